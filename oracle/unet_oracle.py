@@ -1,0 +1,360 @@
+"""CPU oracle for the U-Net denoise hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch, *functional* restatement (plain torch CPU ops over a
+flat ``{name: tensor}`` parameter dict) of the reference algorithm.  It is the
+checker for the HIP path and the ``cpu_baseline`` leg of ``bench.py``; nothing in
+the product package (``simple-diffusion-model_amd/``) may import it.
+
+Pinning: ``tests/golden/make_golden.py`` imports the real reference
+(``/root/reference/models``) in the build container and writes
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every function
+below against those vectors (parity is therefore *pinned*, not "unpinned").
+
+Reference citations (file:line under /root/reference):
+  channel plan ............ models/U_Net.py:41-46
+  forward assembly ........ models/U_Net.py:147-173
+  sinusoid + MLPs ......... models/custom_layers.py:82-98 (layers :59-78)
+  conv block .............. models/custom_layers.py:240-245 (conv -> SiLU -> AdaGN)
+  AdaGN (shift==scale) .... models/custom_layers.py:35-45 (note :41 uses y_scale)
+  residual block .......... models/custom_layers.py:282-287
+  attention ............... models/custom_layers.py:127-163 (softmax(dim=1) = over queries, :147;
+                            self.norm never applied)
+  down / up sample ........ models/custom_layers.py:204-207 / 182-185
+  schedules ............... degraders.py:26-59 (linear), 70-104 (cosine)
+  DDPM / DDIM samplers .... diffusion_sampling_algorithms.py:5-64 / 66-148
+  training step ........... train_diffusion.py:307-366
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- #
+# architecture bookkeeping
+# --------------------------------------------------------------------------- #
+DEFAULT_CFG = dict(
+    num_resnet_blocks=5, in_channel=3, out_channel=3, time_dim=64, cond_dim=None,
+    num_layers=5, attn_layers=[2, 3, 4], num_heads=1, dim_per_head=None, groups=32,
+    min_channel=128, max_channel=512, image_recon=False)
+
+STANDARD_CFG = dict(
+    num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=512, cond_dim=None,
+    num_layers=4, attn_layers=[2, 3], num_heads=1, dim_per_head=None, groups=32,
+    min_channel=128, max_channel=512, image_recon=False)
+
+
+def full_cfg(cfg):
+    out = dict(DEFAULT_CFG)
+    out.update(cfg)
+    return out
+
+
+def channel_plan(cfg):
+    """models/U_Net.py:41-46 — doubles until max_channel."""
+    ch = [cfg["min_channel"]]
+    c = cfg["min_channel"]
+    for _ in range(cfg["num_layers"]):
+        c *= 2
+        ch.append(min(c, cfg["max_channel"]))
+    return ch
+
+
+def param_shapes(cfg):
+    """Ordered {state_dict name: shape} exactly as the reference registers them."""
+    cfg = full_cfg(cfg)
+    ch = channel_plan(cfg)
+    D, cd = cfg["time_dim"], cfg["cond_dim"]
+    L, R = cfg["num_layers"], cfg["num_resnet_blocks"]
+    h = cfg["num_heads"]
+    shapes = {}
+
+    def lin(name, i, o):
+        shapes[name + ".weight"] = (o, i)
+        shapes[name + ".bias"] = (o,)
+
+    def conv(name, i, o, k=3):
+        shapes[name + ".weight"] = (o, i, k, k)
+        shapes[name + ".bias"] = (o,)
+
+    def convblock(name, i, o, emb):
+        conv(name + ".conv_layer.0", i, o)
+        if emb:
+            lin(name + ".adagn.y_scale", D, o)
+            lin(name + ".adagn.y_shift", D, o)
+            shapes[name + ".adagn.group_norm.weight"] = (o,)
+            shapes[name + ".adagn.group_norm.bias"] = (o,)
+
+    def unetblock(name, cin, cout, use_attn, up):
+        for r in range(R):
+            convblock(f"{name}.res_layers.{r}.conv_block_1", cin, cin, D is not None)
+            convblock(f"{name}.res_layers.{r}.conv_block_2", cin, cin, D is not None)
+        for r in range(R):      # ModuleList registration order: all res_layers, then all attn_layers
+            if use_attn:
+                dk = cfg["dim_per_head"] or cin
+                shapes[f"{name}.attn_layers.{r}.norm.weight"] = (cin,)
+                shapes[f"{name}.attn_layers.{r}.norm.bias"] = (cin,)
+                lin(f"{name}.attn_layers.{r}.projection", cin, 3 * h * dk)
+                lin(f"{name}.attn_layers.{r}.output", h * dk, cin)
+        if up:
+            shapes[f"{name}.out_layer.conv_layer.0.weight"] = (cin, cout, 4, 4)
+            shapes[f"{name}.out_layer.conv_layer.0.bias"] = (cout,)
+        else:
+            conv(f"{name}.out_layer.conv_layer.0", cin, cout)
+
+    if D is not None:
+        for j, i in enumerate((0, 2, 4, 6)):
+            lin(f"cond_emb.time_layer.{i}", D, D)
+        if cd is not None:
+            for j, i in enumerate((0, 2, 4, 6)):
+                lin(f"cond_emb.cond_layer.{i}", cd if j == 0 else D, D)
+    convblock("in_layer.0", cfg["in_channel"], ch[0], False)
+    convblock("in_layer.1", ch[0], ch[0], False)
+    for k in range(L):
+        unetblock(f"down_layers.{k}", ch[k], ch[k + 1], k in cfg["attn_layers"], False)
+    convblock("middle_layer.0", ch[-1], ch[-1], False)
+    convblock("middle_layer.1", ch[-1], ch[-1], False)
+    for idx, k in enumerate(range(L - 1, -1, -1)):
+        unetblock(f"up_layers.{idx}", 2 * ch[k + 1], ch[k], k in cfg["attn_layers"], True)
+    convblock("out_layers.0", ch[0], ch[0], False)
+    convblock("out_layers.1", ch[0], cfg["out_channel"], False)
+    return shapes
+
+
+def dead_param_names(cfg):
+    """Parameters that never receive a gradient."""
+    return [n for n in param_shapes(cfg)
+            if ".adagn.y_shift." in n or (".attn_layers." in n and ".norm." in n)]
+
+
+def seeded_params(cfg, seed=0, gain=1.0, dtype=torch.float32):
+    """Deterministic parameters that do not depend on torch's RNG stream:
+    numpy PCG64 per tensor, fan-in-scaled uniform (same family as torch's default
+    initialisers), GroupNorm affine jittered so gamma/beta matter."""
+    import numpy as np
+    params = {}
+    for i, (name, shp) in enumerate(param_shapes(cfg).items()):
+        rng = np.random.default_rng([seed, i])
+        if "group_norm" in name or ".norm." in name:
+            base = 1.0 if name.endswith("weight") else 0.0
+            a = base + 0.2 * rng.standard_normal(shp)
+        else:
+            if len(shp) == 4 and ".out_layer." in name and shp[2] == 4:
+                fan_in = shp[1] * shp[2] * shp[3]   # ConvTranspose2d: torch uses size(1)*k*k
+            elif len(shp) >= 2:
+                fan_in = int(np.prod(shp[1:]))
+            else:
+                fan_in = None
+            if fan_in is None:
+                a = rng.uniform(-0.1, 0.1, shp)
+            else:
+                b = gain / math.sqrt(fan_in)
+                a = rng.uniform(-b, b, shp)
+        params[name] = torch.tensor(a, dtype=dtype)
+    return params
+
+
+# --------------------------------------------------------------------------- #
+# layers
+# --------------------------------------------------------------------------- #
+def silu(x):
+    return x * torch.sigmoid(x)
+
+
+def sinusoid(t, D):
+    """custom_layers.py:84-90."""
+    half = D // 2
+    f = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10_000) / (half - 1)))
+    a = t[:, None] * f[None, :]
+    return torch.cat((a.sin(), a.cos()), dim=1)
+
+
+def mlp4(P, prefix, x):
+    for i in (0, 2, 4):
+        x = silu(F.linear(x, P[f"{prefix}.{i}.weight"], P[f"{prefix}.{i}.bias"]))
+    return F.linear(x, P[f"{prefix}.6.weight"], P[f"{prefix}.6.bias"])
+
+
+def cond_embedding(P, cfg, t, cond=None):
+    emb = mlp4(P, "cond_emb.time_layer", sinusoid(t, cfg["time_dim"]))
+    if cfg["cond_dim"] is not None:
+        emb = emb + mlp4(P, "cond_emb.cond_layer", cond)
+    return emb
+
+
+def adagn(P, name, x, emb):
+    """s * GN(x) + s  with s = y_scale(emb); y_shift is a dead parameter."""
+    xg = F.group_norm(x, 32, P[name + ".group_norm.weight"], P[name + ".group_norm.bias"], 1e-5)
+    s = F.linear(emb, P[name + ".y_scale.weight"], P[name + ".y_scale.bias"])[:, :, None, None]
+    return s * xg + s
+
+
+def conv_block(P, name, x, emb=None, act=True):
+    x = F.conv2d(x, P[name + ".conv_layer.0.weight"], P[name + ".conv_layer.0.bias"], padding=1)
+    if act:
+        x = silu(x)
+    if emb is not None:
+        x = adagn(P, name + ".adagn", x, emb)
+    return x
+
+
+def res_block(P, name, x, emb):
+    y = conv_block(P, name + ".conv_block_1", x, emb)
+    y = conv_block(P, name + ".conv_block_2", y, emb)
+    return y + x
+
+
+def attention(P, name, x, heads, dk):
+    N, C, H, W = x.shape
+    d = dk or C
+    xs = x.reshape(N, C, H * W).transpose(1, 2)                    # [N,S,C]
+    qkv = F.linear(xs, P[name + ".projection.weight"], P[name + ".projection.bias"])
+    qkv = qkv.reshape(N, H * W, heads, 3 * d)
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    q, k, v = (z.permute(0, 2, 1, 3) for z in (q, k, v))           # [N,h,S,d]
+    s = torch.matmul(q, k.transpose(-1, -2)) * d ** -0.5           # [N,h,i,j]
+    p = torch.softmax(s, dim=2)                                    # over queries i
+    o = torch.matmul(p, v).permute(0, 2, 1, 3).reshape(N, H * W, heads * d)
+    o = F.linear(o, P[name + ".output.weight"], P[name + ".output.bias"]) + xs
+    return o.transpose(1, 2).reshape(N, C, H, W)
+
+
+def unet_block(P, cfg, name, x, emb, use_attn, up):
+    for r in range(cfg["num_resnet_blocks"]):
+        x = res_block(P, f"{name}.res_layers.{r}", x, emb)
+        if use_attn:
+            x = attention(P, f"{name}.attn_layers.{r}", x, cfg["num_heads"], cfg["dim_per_head"])
+    w, b = P[f"{name}.out_layer.conv_layer.0.weight"], P[f"{name}.out_layer.conv_layer.0.bias"]
+    if up:
+        x = F.conv_transpose2d(x, w, b, stride=2, padding=1)
+    else:
+        x = F.conv2d(x, w, b, stride=2, padding=1)
+    return silu(x)
+
+
+def unet_forward(P, cfg, x, t=None, cond=None):
+    """models/U_Net.py:147-173."""
+    cfg = full_cfg(cfg)
+    L = cfg["num_layers"]
+    emb = cond_embedding(P, cfg, t, cond) if cfg["time_dim"] is not None else None
+    x = conv_block(P, "in_layer.0", x)
+    x = conv_block(P, "in_layer.1", x)
+    skips = []
+    for k in range(L):
+        x = unet_block(P, cfg, f"down_layers.{k}", x, emb, k in cfg["attn_layers"], False)
+        skips.append(x)
+    x = conv_block(P, "middle_layer.0", x)
+    x = conv_block(P, "middle_layer.1", x)
+    for idx, k in enumerate(range(L - 1, -1, -1)):
+        x = torch.cat((x, skips.pop()), dim=1)
+        x = unet_block(P, cfg, f"up_layers.{idx}", x, emb, k in cfg["attn_layers"], True)
+    x = conv_block(P, "out_layers.0", x)
+    x = conv_block(P, "out_layers.1", x, act=False)
+    if cfg["image_recon"]:
+        x = torch.tanh(x)
+    return x
+
+
+# --------------------------------------------------------------------------- #
+# schedules (degraders.py)
+# --------------------------------------------------------------------------- #
+class LinearSchedule:
+    def __init__(self, beta_1, beta_T, T):
+        self.beta = torch.linspace(beta_1, beta_T, int(T + 1))
+        self.alpha = 1 - self.beta
+        self.abar = torch.cumprod(self.alpha, dim=0)
+
+    def params(self, t):
+        return self.beta[t], self.alpha[t], self.abar[t]
+
+    def alpha_bar(self, t):
+        return self.abar[t]
+
+
+class CosineSchedule:
+    def __init__(self, T=1000):
+        self.T = T
+        self.s = 0.008
+
+    def alpha_bar(self, t):
+        f = lambda u: torch.cos(((u / self.T) + self.s) / (1 + self.s) * (math.pi / 2)) ** 2
+        return f(t) / f(torch.zeros_like(t))
+
+    def params(self, t):
+        ab = self.alpha_bar(t)
+        beta = torch.clip(1 - ab / self.alpha_bar(t - 1), 0.001, 0.999)
+        return beta, 1 - beta, ab
+
+
+def q_sample(sched, x0, t, eps):
+    ab = sched.alpha_bar(t)[:, None, None, None]
+    return ab ** 0.5 * x0 + (1 - ab) ** 0.5 * eps
+
+
+# --------------------------------------------------------------------------- #
+# samplers with injected noise (diffusion_sampling_algorithms.py)
+# --------------------------------------------------------------------------- #
+def ddpm_sample(P, cfg, sched, x_t, noises, min_noise=1, max_noise=1000, labels=None):
+    """noises[i] is the z drawn at loop iteration i (ignored when noise_step <= 1)."""
+    traj = []
+    with torch.no_grad():
+        for i, step in enumerate(range(max_noise, min_noise - 1, -1)):
+            t = torch.tensor([step])
+            beta, alpha, abar = sched.params(t)
+            eps = unet_forward(P, cfg, x_t, t, labels)
+            z = noises[i] if step > 1 else 0
+            x_t = (1 / alpha ** 0.5) * (x_t - ((1 - alpha) / (1 - abar) ** 0.5) * eps) + beta ** 0.5 * z
+            traj.append(x_t)
+    return x_t, traj
+
+
+def ddim_steps(min_noise, max_noise, step):
+    steps = list(range(max_noise, min_noise - 1, -step))
+    if min_noise not in steps:
+        steps.append(min_noise)
+    return steps
+
+
+def ddim_sample(P, cfg, sched, x_t, min_noise=1, max_noise=1000, step=10, labels=None):
+    steps = ddim_steps(min_noise, max_noise, step)
+    traj = []
+    with torch.no_grad():
+        for c, s in enumerate(steps):
+            t = torch.tensor([s])
+            eps = unet_forward(P, cfg, x_t, t, labels)
+            abar = sched.params(t)[2]
+            x0 = (1 / abar ** 0.5) * (x_t - (1 - abar) ** 0.5 * eps)
+            if c < len(steps) - 1:
+                ab1 = sched.params(torch.tensor([steps[c + 1]]))[2]
+                x_t = ab1 ** 0.5 * x0 + (1 - ab1) ** 0.5 * eps      # eta = 0 -> sigma = 0
+                traj.append(x_t)
+    return (x0 if steps[-1] == 1 else x_t), traj
+
+
+# --------------------------------------------------------------------------- #
+# training step (train_diffusion.py:307-366)
+# --------------------------------------------------------------------------- #
+def loss_and_grads(P, cfg, sched, x0, t, eps, labels=None):
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    x_t = q_sample(sched, x0, t, eps)
+    out = unet_forward(leaves, cfg, x_t, t, labels)
+    loss = F.mse_loss(out, eps)
+    loss.backward()
+    return loss.detach(), out.detach(), {k: v.grad for k, v in leaves.items()}
+
+
+class OracleTrainer:
+    """Adam(lr, betas=(0.5, 0.999)) over the live parameters, stock torch CPU."""
+
+    def __init__(self, P, cfg, sched, lr=2e-5):
+        self.cfg, self.sched = cfg, sched
+        self.P = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+        self.opt = torch.optim.Adam(list(self.P.values()), lr=lr, betas=(0.5, 0.999))
+
+    def step(self, x0, t, eps, labels=None):
+        self.opt.zero_grad()
+        out = unet_forward(self.P, self.cfg, q_sample(self.sched, x0, t, eps), t, labels)
+        loss = F.mse_loss(out, eps)
+        loss.backward()
+        self.opt.step()
+        return float(loss)

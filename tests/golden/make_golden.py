@@ -1,0 +1,299 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from
+/root/reference, CPU) on seeded inputs.  Run only in the build container:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference itself never travels; only the input/output vectors written here do.
+Weights are not stored: they are regenerated from ``oracle.unet_oracle.seeded_params``
+(numpy PCG64, independent of torch's RNG stream) on both sides.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+from oracle import unet_oracle as O  # noqa: E402
+
+sys.path.insert(0, "/root/reference")
+sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))  # imported, never used numerically
+from models.U_Net import U_Net  # noqa: E402
+from models import custom_layers as RL  # noqa: E402
+import degraders as RD  # noqa: E402
+import diffusion_sampling_algorithms as RS  # noqa: E402
+
+torch.set_num_threads(8)
+
+MODEL_CASES = {
+    # name: (cfg, N, H, W, gain)
+    "narrow_cond": (dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=32, cond_dim=3,
+                         num_layers=2, attn_layers=[1], num_heads=2, dim_per_head=16,
+                         min_channel=32, max_channel=64), 3, 16, 24, 1.0),
+    "narrow_gain": (dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=32, cond_dim=3,
+                         num_layers=2, attn_layers=[1], num_heads=2, dim_per_head=16,
+                         min_channel=32, max_channel=64), 2, 16, 16, 1.8),
+    "deep_uncond": (dict(num_resnet_blocks=2, in_channel=3, out_channel=3, time_dim=64, cond_dim=None,
+                         num_layers=3, attn_layers=[0, 2], num_heads=1, dim_per_head=None,
+                         min_channel=32, max_channel=64), 2, 16, 8, 1.5),
+    "sr_recon": (dict(num_resnet_blocks=1, in_channel=6, out_channel=3, time_dim=32, cond_dim=None,
+                      num_layers=2, attn_layers=[0, 1], num_heads=1, dim_per_head=None,
+                      min_channel=32, max_channel=32, image_recon=True), 2, 8, 8, 1.8),
+    "no_emb": (dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=None, cond_dim=None,
+                    num_layers=2, attn_layers=[1], num_heads=1, dim_per_head=8,
+                    min_channel=32, max_channel=64), 2, 8, 12, 1.5),
+}
+
+
+def ref_model(cfg, P):
+    m = U_Net(**cfg)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(P.keys()), "oracle.param_shapes order != reference state_dict order"
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(P[k].shape), k
+    m.load_state_dict({k: v.clone() for k, v in P.items()}, strict=True)
+    return m
+
+
+def sample_idx(numel, seed, n=128):
+    rng = np.random.default_rng([977, seed])
+    return rng.integers(0, numel, size=min(n, numel))
+
+
+def model_case(name, cfg, N, H, W, gain):
+    full = O.full_cfg(cfg)
+    P = O.seeded_params(full, seed=3, gain=gain)
+    m = ref_model(full, P)
+    rng = np.random.default_rng([11, len(name)])
+    x = torch.tensor(rng.standard_normal((N, full["in_channel"], H, W)), dtype=torch.float32)
+    t = torch.tensor(rng.integers(1, 1000, size=(N,)), dtype=torch.int64)
+    cond = None
+    if full["cond_dim"] is not None:
+        cond = torch.tensor(np.eye(full["cond_dim"])[rng.integers(0, full["cond_dim"], N)], dtype=torch.float32)
+    target = torch.tensor(rng.standard_normal((N, full["out_channel"], H, W)), dtype=torch.float32)
+
+    m.eval()
+    with torch.no_grad():
+        y_eval = m(x, t if full["time_dim"] is not None else None, cond)
+        # batch-1 embedding broadcast (sampler call convention, quirk 7)
+        if full["time_dim"] is not None:
+            t1 = t[:1]
+            c1 = cond[0] if cond is not None else None      # shape (cond_dim,) like the generator passes
+            y_b1 = m(x, t1, c1)
+        else:
+            y_b1 = y_eval
+    m.train()
+    m.zero_grad()
+    y = m(x, t if full["time_dim"] is not None else None, cond)
+    loss = torch.nn.functional.mse_loss(y, target)
+    loss.backward()
+    out = dict(cfg=json.dumps(full), gain=gain, x=x.numpy(), t=t.numpy(), target=target.numpy(),
+               y=y_eval.numpy(), y_b1=y_b1.numpy(), loss=float(loss))
+    if cond is not None:
+        out["cond"] = cond.numpy()
+    dead = []
+    for i, (k, p) in enumerate(m.named_parameters()):
+        if p.grad is None:
+            dead.append(k)
+            continue
+        g = p.grad.detach().double().flatten()
+        idx = sample_idx(g.numel(), i)
+        out[f"gidx/{k}"] = idx
+        out[f"gval/{k}"] = g[idx].float().numpy()
+        out[f"gstat/{k}"] = np.array([float(g.sum()), float(g.abs().sum()), float(g.norm())])
+    out["dead"] = json.dumps(dead)
+    assert dead == O.dead_param_names(full), (dead[:3], O.dead_param_names(full)[:3])
+    np.savez(os.path.join(HERE, f"model_{name}.npz"), **out)
+    print(name, "params", sum(p.numel() for p in m.parameters()), "loss", float(loss),
+          "mean|y|", float(y_eval.abs().mean()))
+
+
+def block_cases():
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g)
+
+    def put(prefix, mod, **tensors):
+        for k, v in mod.state_dict().items():
+            out[f"{prefix}/p/{k}"] = v.numpy().copy()
+        for k, v in tensors.items():
+            out[f"{prefix}/{k}"] = v.detach().numpy().copy()
+
+    def randomise(mod, scale=1.0):
+        with torch.no_grad():
+            for n_, p in mod.named_parameters():
+                if p.dim() == 1:
+                    p.copy_(0.3 * r(*p.shape) + (1.0 if "norm" in n_ and n_.endswith("weight") else 0.0))
+                else:
+                    p.copy_(r(*p.shape) * scale / (p[0].numel() ** 0.5))
+
+    # attention: large logits so the softmax axis matters
+    for tag, C, heads, dk, H, W in (("attn_h2", 32, 2, 16, 5, 7), ("attn_h1", 32, 1, None, 5, 7)):
+        a = RL.AttentionBlock(C, heads=heads, d_k=dk)
+        randomise(a)
+        with torch.no_grad():
+            a.projection.weight.mul_(12.0)
+        x = r(2, C, H, W).requires_grad_(True)
+        y = a(x)
+        dy = r(*y.shape)
+        y.backward(dy)
+        put(tag, a, x=x, y=y, dy=dy, dx=x.grad,
+            dproj_w=a.projection.weight.grad, dproj_b=a.projection.bias.grad,
+            dout_w=a.output.weight.grad, dout_b=a.output.bias.grad)
+
+    # AdaGN (emb batch N and batch 1)
+    ag = RL.AdaGN(16, 64)
+    randomise(ag)
+    x = r(3, 64, 6, 10).requires_grad_(True)
+    emb = r(3, 16).requires_grad_(True)
+    y = ag(x, emb)
+    dy = r(*y.shape)
+    y.backward(dy)
+    put("adagn", ag, x=x, emb=emb, y=y, dy=dy, dx=x.grad, demb=emb.grad,
+        dys_w=ag.y_scale.weight.grad, dys_b=ag.y_scale.bias.grad,
+        dgn_w=ag.group_norm.weight.grad, dgn_b=ag.group_norm.bias.grad)
+    with torch.no_grad():
+        out["adagn/y_b1"] = ag(x, emb[:1]).numpy().copy()
+
+    # conv block with embedding, residual block
+    cb = RL.UNet_ConvBlock(32, 64, use_activation=True, emb_dim=16)
+    randomise(cb)
+    x = r(2, 32, 6, 10).requires_grad_(True)
+    emb = r(2, 16)
+    y = cb(x, emb)
+    dy = r(*y.shape)
+    y.backward(dy)
+    put("convblock", cb, x=x, emb=emb, y=y, dy=dy, dx=x.grad, dw=cb.conv_layer[0].weight.grad,
+        db=cb.conv_layer[0].bias.grad)
+
+    rb = RL.ResidualBlock(32, 32, emb_dim=16)
+    randomise(rb)
+    x = r(2, 32, 6, 10).requires_grad_(True)
+    y = rb(x, emb)
+    dy = r(*y.shape)
+    y.backward(dy)
+    put("resblock", rb, x=x, emb=emb, y=y, dy=dy, dx=x.grad)
+
+    dn = RL.DownsampleBlock(32, 64)
+    randomise(dn)
+    x = r(2, 32, 6, 10).requires_grad_(True)
+    y = dn(x)
+    dy = r(*y.shape)
+    y.backward(dy)
+    put("down", dn, x=x, y=y, dy=dy, dx=x.grad, dw=dn.conv_layer[0].weight.grad, db=dn.conv_layer[0].bias.grad)
+
+    up = RL.UpsampleBlock(64, 32)
+    randomise(up)
+    x = r(2, 64, 3, 5).requires_grad_(True)
+    y = up(x)
+    dy = r(*y.shape)
+    y.backward(dy)
+    put("up", up, x=x, y=y, dy=dy, dx=x.grad, dw=up.conv_layer[0].weight.grad, db=up.conv_layer[0].bias.grad)
+
+    for tag, cd in (("emb_t", None), ("emb_tc", 5)):
+        ce = RL.ConditionalEmbedding(32, cd)
+        randomise(ce)
+        t = torch.tensor([1, 500, 1000])
+        cond = r(3, cd) if cd else None
+        y = ce(t, cond)
+        kw = dict(t=t, y=y)
+        if cd:
+            kw["cond"] = cond
+        put(tag, ce, **kw)
+    np.savez(os.path.join(HERE, "blocks.npz"), **out)
+    print("blocks:", len(out), "arrays")
+
+
+def schedule_and_sampler_cases():
+    out = {}
+    ts = torch.tensor([1, 2, 500, 999, 1000])
+    lin = RD.NoiseDegradation(5e-3, 9e-3, 1000)
+    cos = RD.CosineNoiseDegradation(1000)
+    for tag, s in (("lin", lin), ("cos", cos)):
+        b, a, ab = s.get_timestep_params(ts)
+        out[f"sched/{tag}"] = torch.stack([b, a, ab]).numpy()
+    out["sched/ts"] = ts.numpy()
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(3, 3, 8, 8, generator=g)
+    eps = torch.randn(3, 3, 8, 8, generator=g)
+    tq = torch.tensor([1, 400, 1000])
+    out["q/x0"], out["q/eps"], out["q/t"] = x0.numpy(), eps.numpy(), tq.numpy()
+    out["q/lin"] = lin(x0, tq, eps).numpy()
+    out["q/cos"] = cos(x0, tq, eps).numpy()
+
+    cfg = O.full_cfg(MODEL_CASES["narrow_cond"][0])
+    P = O.seeded_params(cfg, seed=3, gain=1.8)
+    m = ref_model(cfg, P)
+    xT = torch.randn(2, 3, 8, 8, generator=g)
+    labels = torch.tensor([0.0, 1.0, 0.0])            # shape (cond_dim,), as generate_images_diffusion.py:183
+    quiet = lambda *a, **k: None
+    out["samp/xT"], out["samp/labels"] = xT.numpy(), labels.numpy()
+
+    for tag, sch in (("lin", lin), ("cos", cos)):
+        # DDPM over steps 6..1 ; z drawn by torch.randn(shape) after each forward
+        torch.manual_seed(77)
+        x_end = RS.ddpm_sampling(m, sch, xT.clone(), min_noise=1, max_noise=6, labels_tensor=labels, log=quiet)
+        torch.manual_seed(77)
+        zs = torch.stack([torch.randn(xT.shape) for _ in range(5)])
+        out[f"samp/ddpm_{tag}_z"] = zs.numpy()
+        out[f"samp/ddpm_{tag}_out"] = x_end.numpy()
+    # DDIM 1000 -> 1 in steps of 250 (+[1]) : [1000, 750, 500, 250, 1]
+    for tag, sch in (("lin", lin), ("cos", cos)):
+        torch.manual_seed(78)
+        x_end = RS.ddim_sampling(m, sch, xT.clone(), min_noise=1, max_noise=1000, labels_tensor=labels,
+                                 ddim_step_size=250, log=quiet)
+        out[f"samp/ddim_{tag}_out"] = x_end.numpy()
+    # DDIM whose last step is not 1 (returns x_t, not x0): min_noise=3
+    torch.manual_seed(79)
+    x_end = RS.ddim_sampling(m, lin, xT.clone(), min_noise=3, max_noise=13, labels_tensor=labels,
+                             ddim_step_size=5, log=quiet)
+    out["samp/ddim_min3_out"] = x_end.numpy()
+    np.savez(os.path.join(HERE, "schedules_samplers.npz"), **out)
+    print("schedules/samplers:", len(out), "arrays")
+
+
+def train_case():
+    """3 Adam steps of the reference training-step body (train_diffusion.py:307-366) on the narrow net."""
+    cfg = O.full_cfg(MODEL_CASES["narrow_cond"][0])
+    P = O.seeded_params(cfg, seed=3, gain=1.8)
+    m = ref_model(cfg, P)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=2e-3, betas=(0.5, 0.999))
+    cos = RD.CosineNoiseDegradation(1000)
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    losses = []
+    for i in range(3):
+        x0 = torch.randn(4, 3, 16, 16, generator=g)
+        eps = torch.randn(4, 3, 16, 16, generator=g)
+        t = torch.randint(1, 1000, (4,), generator=g)
+        lab = torch.eye(3)[torch.randint(0, 3, (4,), generator=g)]
+        opt.zero_grad()
+        x_t = cos(x0, t, eps)
+        loss = torch.nn.functional.mse_loss(m(x_t, t, lab), eps)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        out[f"x0_{i}"], out[f"eps_{i}"], out[f"t_{i}"], out[f"lab_{i}"] = x0.numpy(), eps.numpy(), t.numpy(), lab.numpy()
+    out["losses"] = np.array(losses)
+    for i, (k, v) in enumerate(m.state_dict().items()):
+        v = v.double().flatten()
+        idx = sample_idx(v.numel(), i)
+        out[f"pidx/{k}"] = idx
+        out[f"pval/{k}"] = v[idx].float().numpy()
+        out[f"pstat/{k}"] = np.array([float(v.sum()), float(v.abs().sum())])
+    np.savez(os.path.join(HERE, "train_narrow.npz"), **out)
+    print("train losses", losses)
+
+
+if __name__ == "__main__":
+    for name, (cfg, N, H, W, gain) in MODEL_CASES.items():
+        model_case(name, cfg, N, H, W, gain)
+    block_cases()
+    schedule_and_sampler_cases()
+    train_case()

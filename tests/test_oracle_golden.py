@@ -1,0 +1,153 @@
+"""The CPU oracle (oracle/unet_oracle.py) against vectors produced by the real
+reference (tests/golden/make_golden.py).  Pure CPU; runs in the build container
+and on the GPU box alike (never reads /root/reference)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+CASES = ["narrow_cond", "narrow_gain", "deep_uncond", "sr_recon", "no_emb"]
+RTOL, ATOL = 1e-3, 1e-4     # north_star gate; the oracle is far inside it (asserted tighter below)
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_matches_reference(case):
+    g = load(f"model_{case}.npz")
+    cfg = json.loads(str(g["cfg"]))
+    P = O.seeded_params(cfg, seed=3, gain=float(g["gain"]))
+    x, t = T(g["x"]), T(g["t"])
+    cond = T(g["cond"]) if "cond" in g else None
+    with torch.no_grad():
+        y = O.unet_forward(P, cfg, x, t if cfg["time_dim"] is not None else None, cond)
+    ref = T(g["y"])
+    assert torch.allclose(y, ref, rtol=1e-4, atol=2e-6), float((y - ref).abs().max())
+    rel = float((y - ref).norm() / ref.norm())
+    assert rel < 1e-5
+    if cfg["time_dim"] is not None:   # batch-1 embedding broadcast
+        with torch.no_grad():
+            yb = O.unet_forward(P, cfg, x, t[:1], cond[0] if cond is not None else None)
+        assert torch.allclose(yb, T(g["y_b1"]), rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_grads_match_reference(case):
+    g = load(f"model_{case}.npz")
+    cfg = json.loads(str(g["cfg"]))
+    P = {k: v.requires_grad_(True) for k, v in O.seeded_params(cfg, seed=3, gain=float(g["gain"])).items()}
+    x, t = T(g["x"]), T(g["t"])
+    cond = T(g["cond"]) if "cond" in g else None
+    y = O.unet_forward(P, cfg, x, t if cfg["time_dim"] is not None else None, cond)
+    loss = torch.nn.functional.mse_loss(y, T(g["target"]))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    dead = json.loads(str(g["dead"]))
+    assert dead == O.dead_param_names(cfg)
+    for k, p in P.items():
+        if k in dead:
+            assert p.grad is None
+            continue
+        gr = p.grad.double().flatten()
+        ref = T(g[f"gval/{k}"]).double()
+        got = gr[T(g[f"gidx/{k}"])]
+        scale = float(g[f"gstat/{k}"][2]) / max(1.0, gr.numel() ** 0.5)
+        assert float((got - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-2 * scale + 1e-9, k
+        assert abs(float(gr.norm()) - float(g[f"gstat/{k}"][2])) <= 1e-4 * float(g[f"gstat/{k}"][2]) + 1e-9, k
+
+
+def _params(b, prefix):
+    return {k[len(prefix) + 3:]: T(b[k]) for k in b.files if k.startswith(prefix + "/p/")}
+
+
+def test_blocks_match_reference():
+    b = load("blocks.npz")
+    # attention with large logits pins the softmax axis and the qkv chunk layout
+    for tag, heads, dk in (("attn_h2", 2, 16), ("attn_h1", 1, None)):
+        P = {"a." + k: v for k, v in _params(b, tag).items()}
+        x = T(b[f"{tag}/x"]).requires_grad_(True)
+        y = O.attention(P, "a", x, heads, dk)
+        ref = T(b[f"{tag}/y"])
+        assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4), float((y - ref).abs().max())
+        y.backward(T(b[f"{tag}/dy"]))
+        assert torch.allclose(x.grad, T(b[f"{tag}/dx"]), rtol=1e-3, atol=1e-3)
+        # wrong axis must be far away (sanity of the fixture)
+        xs = x.detach()
+        N, C, H, W = xs.shape
+    P = {"g." + k: v for k, v in _params(b, "adagn").items()}
+    y = O.adagn(P, "g", T(b["adagn/x"]), T(b["adagn/emb"]))
+    assert torch.allclose(y, T(b["adagn/y"]), rtol=1e-4, atol=1e-5)
+    y1 = O.adagn(P, "g", T(b["adagn/x"]), T(b["adagn/emb"])[:1])
+    assert torch.allclose(y1, T(b["adagn/y_b1"]), rtol=1e-4, atol=1e-5)
+    P = {"c." + k: v for k, v in _params(b, "convblock").items()}
+    y = O.conv_block(P, "c", T(b["convblock/x"]), T(b["convblock/emb"]))
+    assert torch.allclose(y, T(b["convblock/y"]), rtol=1e-4, atol=1e-5)
+    P = {"r." + k: v for k, v in _params(b, "resblock").items()}
+    y = O.res_block(P, "r", T(b["resblock/x"]), T(b["resblock/emb"]))
+    assert torch.allclose(y, T(b["resblock/y"]), rtol=1e-4, atol=1e-5)
+    for tag, cd in (("emb_t", None), ("emb_tc", 5)):
+        P = {"cond_emb." + k: v for k, v in _params(b, tag).items()}
+        cfg = dict(time_dim=32, cond_dim=cd)
+        y = O.cond_embedding(P, cfg, T(b[f"{tag}/t"]), T(b[f"{tag}/cond"]) if cd else None)
+        assert torch.allclose(y, T(b[f"{tag}/y"]), rtol=1e-4, atol=1e-5)
+
+
+def test_schedules_and_qsample():
+    s = load("schedules_samplers.npz")
+    ts = T(s["sched/ts"])
+    lin, cos = O.LinearSchedule(5e-3, 9e-3, 1000), O.CosineSchedule(1000)
+    for tag, sch in (("lin", lin), ("cos", cos)):
+        got = torch.stack(sch.params(ts))
+        assert torch.allclose(got, T(s[f"sched/{tag}"]), rtol=1e-6, atol=1e-12), tag
+        q = O.q_sample(sch, T(s["q/x0"]), T(s["q/t"]), T(s["q/eps"]))
+        assert torch.allclose(q, T(s[f"q/{tag}"]), rtol=1e-6, atol=1e-7)
+    # SURVEY a15 known values
+    b, a, ab = cos.params(torch.tensor([1, 500, 1000]))
+    assert abs(float(ab[0]) - 0.99995875) < 1e-6 and abs(float(ab[1]) - 0.49384364) < 1e-6
+    assert abs(float(b[1]) - 0.00314564) < 1e-7 and float(b[2]) == pytest.approx(0.999)
+
+
+def test_sampler_trajectories():
+    s = load("schedules_samplers.npz")
+    cfg = O.full_cfg(dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=32, cond_dim=3,
+                          num_layers=2, attn_layers=[1], num_heads=2, dim_per_head=16,
+                          min_channel=32, max_channel=64))
+    P = O.seeded_params(cfg, seed=3, gain=1.8)
+    xT, labels = T(s["samp/xT"]), T(s["samp/labels"])
+    lin, cos = O.LinearSchedule(5e-3, 9e-3, 1000), O.CosineSchedule(1000)
+    for tag, sch in (("lin", lin), ("cos", cos)):
+        z = T(s[f"samp/ddpm_{tag}_z"])
+        out, _ = O.ddpm_sample(P, cfg, sch, xT, list(z) + [None], 1, 6, labels)
+        assert torch.allclose(out, T(s[f"samp/ddpm_{tag}_out"]), rtol=1e-4, atol=1e-5), tag
+        out, _ = O.ddim_sample(P, cfg, sch, xT, 1, 1000, 250, labels)
+        ref = T(s[f"samp/ddim_{tag}_out"])
+        # cosine: first step divides by sqrt(alpha_bar_T) ~ 4e-8 -> relative comparison only
+        assert float((out - ref).norm() / ref.norm()) < 1e-3, tag
+    out, _ = O.ddim_sample(P, cfg, lin, xT, 3, 13, 5, labels)
+    assert torch.allclose(out, T(s["samp/ddim_min3_out"]), rtol=1e-4, atol=1e-5)
+    assert O.ddim_steps(1, 1000, 20)[:2] == [1000, 980] and len(O.ddim_steps(1, 1000, 20)) == 51
+
+
+def test_training_steps():
+    g = load("train_narrow.npz")
+    cfg = O.full_cfg(dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=32, cond_dim=3,
+                          num_layers=2, attn_layers=[1], num_heads=2, dim_per_head=16,
+                          min_channel=32, max_channel=64))
+    tr = O.OracleTrainer(O.seeded_params(cfg, seed=3, gain=1.8), cfg, O.CosineSchedule(1000), lr=2e-3)
+    for i in range(3):
+        loss = tr.step(T(g[f"x0_{i}"]), T(g[f"t_{i}"]), T(g[f"eps_{i}"]), T(g[f"lab_{i}"]))
+        assert abs(loss - float(g["losses"][i])) < 2e-5
+    for k, v in tr.P.items():
+        got = v.detach().double().flatten()[T(g[f"pidx/{k}"])]
+        assert torch.allclose(got, T(g[f"pval/{k}"]).double(), rtol=1e-3, atol=2e-5), k
