@@ -1,0 +1,255 @@
+/*
+ * sdm_hip.h — C ABI of libsdm_hip.so, the MI355X (gfx950) kernel library behind the
+ * U-Net denoise hot path of Simple-Diffusion-Model.
+ *
+ * The reference has no FFI layer (it is pure PyTorch), so every entry
+ * point below replaces one *class of torch op* that the reference's
+ * models/custom_layers.py dispatches; the citation on each function is the reference
+ * call site it stands in for.  The Python host (simple-diffusion-model_amd/sdm_hip/)
+ * binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (tensor.data_ptr()); fp32 unless stated
+ *   - activations are NHWC ("pixel rows x channels") inside the library; NCHW only at
+ *     sdm_stem_conv (input) and sdm_head_conv (output)
+ *   - conv weights are tap-major:  w[ky][kx][c_out][c_in]   (Conv2d and ConvTranspose2d
+ *     alike; the PyTorch-shaped parameter is a strided *view* of that storage)
+ *   - launch functions never allocate, synchronise or copy host<->device: they are
+ *     safe inside hipGraph stream capture.  Scratch comes from the caller (ws).
+ *   - return value: 0 = ok, <0 = error (sdm_last_error() gives the text, thread-local)
+ */
+#ifndef SDM_HIP_H
+#define SDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sdm_stream_t; /* hipStream_t */
+
+#define SDM_OK 0
+#define SDM_ERR_ARG (-1)
+#define SDM_ERR_LAUNCH (-2)
+#define SDM_ERR_UNSUPPORTED (-3)
+
+#define SDM_ACT_NONE 0
+#define SDM_ACT_SILU 1
+#define SDM_ACT_TANH 2
+
+#define SDM_MAX_PHASE 4
+#define SDM_MAX_TAPS 16
+
+int sdm_version(void);
+const char* sdm_last_error(void);
+/* out[0]=CU count, out[1]=LDS bytes per CU-workgroup limit, out[2]=wave size, out[3]=1 if arch is gfx950 */
+int sdm_device_info(int* out4);
+/* sizeof the ABI structs (0 igemm desc, 1 wgrad desc, 2 rows, 3 linear job, 4 adam job) so a binding can assert its layout */
+size_t sdm_struct_size(int which);
+
+/* A logical matrix of "pixel rows x channels", optionally the channel-concat of two
+ * tensors (U_Net.py:168 torch.cat) and optionally carrying a pending per-(image,channel)
+ * affine v*scale+shift (the deferred GroupNorm+AdaGN of custom_layers.py:35-45) that is
+ * applied when the rows are loaded; out-of-image taps stay exactly zero. */
+typedef struct sdm_rows {
+  const float* p0;     /* channels [0, csplit) */
+  const float* p1;     /* channels [csplit, C); NULL when not a concat */
+  int csplit;          /* = C when p1 == NULL */
+  int64_t ld0, ld1;    /* row pitch in floats */
+  const float* scale;  /* [n][C] or [1][C]; NULL = no affine */
+  const float* shift;
+  int aff_nstride;     /* C for per-image tables, 0 for a broadcast (batch-1 embedding) table */
+  int H, W;            /* spatial dims of the rows: row = (n*H + y)*W + x ; plain matrix: H=rows, W=1 */
+} sdm_rows;
+
+/* Implicit-GEMM contraction on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
+ *
+ *   out[opix(m)][j] = epi( alpha * sum_{tap} sum_{c<K}  A[ipix(m,tap)][c] * Wt[tap][j][c] )
+ *
+ * m runs over the tile grid (n, y, x) of (Ht, Wt) per image; ipix = (n, y*sstride+dy, x*sstride+dx)
+ * inside a's (H, W); opix = (n, y*ostride+oy, x*ostride+ox) inside (Ho, Wo).
+ * Serves: Conv2d k3 s1/s2 (custom_layers.py:222-227,195-200), ConvTranspose2d k4 s2 p1 as 4
+ * sub-pixel phases (:173-178), nn.Linear on [N,S,C] tokens (:138,:156), the attention
+ * einsums (:144,:150), and every data-gradient of those (b_kmajor selects W used as [k][j]).
+ *
+ * epi(v): v += bias[j]; z=v (stored to out_preact if given); v = act(v);
+ *         v += res[opix][j] + res2[opix][j]; v *= silu'(dact_z[opix][j]); store.
+ */
+typedef struct sdm_igemm_desc {
+  int M;      /* images * Ht * Wt (rows of the tile grid, per batch entry) */
+  int N;      /* output channels */
+  int K;      /* reduction channels per tap */
+  int batch;  /* independent GEMMs (attention: images*heads); 1 otherwise */
+  int bdiv;   /* batch b -> (b / bdiv, b % bdiv) for the two-level strides below (>=1) */
+
+  sdm_rows a;
+  int64_t a_bs0, a_bs1; /* batch strides of a.p0 (floats) */
+  int Ht, Wt;           /* tile grid per image (M = images*Ht*Wt) */
+  int sstride;          /* source = tile*sstride + d */
+  int nphase;           /* 1, or 4 for sub-pixel phases */
+  int ntaps[SDM_MAX_PHASE];
+  int8_t tap_dy[SDM_MAX_PHASE][SDM_MAX_TAPS];
+  int8_t tap_dx[SDM_MAX_PHASE][SDM_MAX_TAPS];
+  uint8_t tap_w[SDM_MAX_PHASE][SDM_MAX_TAPS]; /* weight slice index of the tap */
+
+  const float* b;        /* weights */
+  int64_t ldb;           /* pitch of one weight row */
+  int64_t b_tap_stride;  /* floats between tap slices */
+  int b_kmajor;          /* 0: Wt[tap][j][c] (c contiguous)   1: Wt[tap][c][j] (j contiguous) */
+  int64_t b_bs0, b_bs1;
+
+  int ostride, Ho, Wo;   /* output geometry */
+  int ph_oy[SDM_MAX_PHASE], ph_ox[SDM_MAX_PHASE];
+  float* out;
+  int64_t ldo;
+  int64_t o_bs0, o_bs1;
+
+  float alpha;
+  const float* bias;      /* [N] or NULL */
+  int act;                /* SDM_ACT_* */
+  float* out_preact;      /* NULL or same geometry as out (pitch ldo): pre-activation copy for backward */
+  const float* res;       /* NULL or addend with pitch ldres at opix */
+  int64_t ldres;
+  int64_t r_bs0, r_bs1;
+  const float* res2;      /* NULL or second addend (pitch ldres2) */
+  int64_t ldres2;
+  const float* dact_z;    /* NULL or pre-activation of the tensor whose gradient this is (pitch ldz) */
+  int64_t ldz;
+  int dact_ncols;         /* silu'(z) is applied to output columns [0, dact_ncols); 0 = all N */
+
+  float* ws;              /* split-K scratch: M_out_rows*N floats, used only when the library splits K */
+  size_t ws_bytes;
+} sdm_igemm_desc;
+
+int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream);
+/* scratch the library may want for this problem (0 if it will not split K) */
+size_t sdm_igemm_workspace_bytes(const sdm_igemm_desc* d);
+
+/* Weight-gradient contraction (autograd of Conv2d / ConvTranspose2d / Linear weight,
+ * train_diffusion.py:358):  K runs over pixels.
+ *
+ *   dw[tap][i][j] (+)= sum_{p in (images,Hk,Wk)}  G[gpix(p,tap)][i] * X[xpix(p,tap)][j]
+ */
+typedef struct sdm_wgrad_desc {
+  int M;          /* rows of dw per tap (output channels of the forward op) */
+  int N;          /* cols of dw per tap (input channels of the forward op) */
+  int images, Hk, Wk; /* reduction grid */
+  int batch, bdiv;
+  sdm_rows g;     /* gradient rows (channels = M) */
+  int g_stride;   /* g source = p*g_stride + tap_gd */
+  sdm_rows x;     /* activation rows (channels = N), may carry affine / concat */
+  int x_stride;
+  int64_t g_bs0, g_bs1, x_bs0, x_bs1;
+  int ntaps;
+  int8_t g_dy[SDM_MAX_TAPS], g_dx[SDM_MAX_TAPS];
+  int8_t x_dy[SDM_MAX_TAPS], x_dx[SDM_MAX_TAPS];
+  uint8_t tap_w[SDM_MAX_TAPS];
+  float* dw;
+  int64_t ldw, w_tap_stride;
+  int64_t w_bs0, w_bs1;
+  float alpha;
+  int accumulate; /* 0: dw is overwritten (library zeroes it first if it splits K); 1: added into */
+} sdm_wgrad_desc;
+
+int sdm_wgrad(const sdm_wgrad_desc* d, sdm_stream_t stream);
+
+/* in_layer.0 (U_Net.py:55-60): Conv2d(Cin<=8 -> C, k3 p1) + SiLU, NCHW image in, NHWC rows out.
+ * out_preact optional (training). */
+int sdm_stem_conv(const float* x_nchw, const float* w_tap, const float* bias, float* out_nhwc,
+                  float* out_preact, int images, int Cin, int H, int W, int Cout, int act, sdm_stream_t s);
+/* out_layers.1 (+Tanh) (U_Net.py:121-128): Conv2d(C -> Cout<=8, k3 p1), NHWC rows in, NCHW out. */
+int sdm_head_conv(const float* x_nhwc, const float* w_tap, const float* bias, float* out_nchw,
+                  int images, int Cin, int H, int W, int Cout, int act, sdm_stream_t s);
+/* data-gradient of the head conv: dy NCHW [images,Cout,H,W] -> dx NHWC [rows][Cin], times silu'(z). */
+int sdm_head_conv_dgrad(const float* dy_nchw, const float* w_tap, float* dx_nhwc, const float* dact_z,
+                        int images, int Cin, int H, int W, int Cout, sdm_stream_t s);
+/* weight/bias gradient of stem (x NCHW, g NHWC) and head (x NHWC, g NCHW); dw tap-major. */
+int sdm_stem_conv_wgrad(const float* x_nchw, const float* g_nhwc, float* dw_tap, float* dbias,
+                        int images, int Cin, int H, int W, int Cout, sdm_stream_t s);
+int sdm_head_conv_wgrad(const float* x_nhwc, const float* g_nchw, float* dw_tap, float* dbias,
+                        int images, int Cin, int H, int W, int Cout, sdm_stream_t s);
+
+/* GroupNorm(32) statistics of y [images][HW][C] folded with the AdaGN modulation into the
+ * per-(image,channel) affine that consumers apply on load (custom_layers.py:35-45, quirk: shift==scale):
+ *   scale[n][c] = rstd*gamma[c]*s ,  shift[n][c] = (beta[c] - mean*rstd*gamma[c])*s + s ,  s = mod[n or 0][c]
+ * mean/rstd [images][groups] are also written (backward needs them). */
+int sdm_gn_affine(const float* y, int64_t ldy, int images, int HW, int C, int groups, float eps,
+                  const float* gamma, const float* beta, const float* mod, int mod_nstride,
+                  float* scale, float* shift, float* mean, float* rstd, sdm_stream_t s);
+
+/* out[r][c] = scale[n][c]*y[r][c] + shift[n][c] + cat(x0,x1)[r][c]   (ResidualBlock tail, custom_layers.py:284-286) */
+int sdm_affine_residual(const float* y, int64_t ldy, const float* scale, const float* shift, int aff_nstride,
+                        const float* x0, int64_t ldx0, const float* x1, int64_t ldx1, int csplit,
+                        float* out, int64_t ldo, int images, int HW, int C, sdm_stream_t s);
+
+/* Backward of y -> (scale*y+shift) with GroupNorm statistics and modulation (AdaGN backward):
+ *   given dout (gradient w.r.t. the affine'd tensor), y, z (pre-SiLU of y, may be NULL):
+ *   dz = silu'(z) * rstd*( dout*s*gamma - mean_g(dout*s*gamma) - xhat*mean_g(dout*s*gamma*xhat) )
+ *   dmod[n][c]   = sum_hw dout*(xhat*gamma+beta+1)
+ *   dgamma[c] += sum_{n,hw} dout*s*xhat ; dbeta[c] += sum_{n,hw} dout*s
+ * ws: images*C*5 floats. */
+int sdm_gn_adagn_bwd(const float* dout, int64_t lddo, const float* y, int64_t ldy, const float* z, int64_t ldz,
+                     int images, int HW, int C, int groups, const float* gamma, const float* beta,
+                     const float* mod, int mod_nstride, const float* mean, const float* rstd,
+                     float* dz, int64_t lddz, float* dmod, float* dgamma, float* dbeta, float* ws, sdm_stream_t s);
+
+/* Column softmax of attention scores (custom_layers.py:147: softmax(dim=1) = over QUERIES i for each key j).
+ * scores [batch][S][lds] in place. */
+int sdm_col_softmax(float* scores, int batch, int S, int64_t lds, sdm_stream_t s);
+/* backward: ds = scale * p * (dp - sum_i p*dp) per column, in place on dp. */
+int sdm_col_softmax_bwd(const float* p, float* dp, int batch, int S, int64_t lds, float scale, sdm_stream_t s);
+
+/* Sinusoidal timestep features (custom_layers.py:84-90): out[n][D] = [sin(t f_i) | cos(t f_i)]. t is int64;
+ * freq[D/2] is the frequency table exp(-i ln(1e4)/(D/2-1)), computed once on the host exactly as the reference does. */
+int sdm_sinusoid(const int64_t* t, const float* freq, int n, int D, float* out, sdm_stream_t s);
+/* Small-batch Linear (+SiLU) for the embedding MLPs and the y_scale projections
+ * (custom_layers.py:59-78, :38): out[m][o] = act(sum_k x[m][k] w[o][k] + b[o]) (+ add[m][o]). */
+int sdm_linear_small(const float* x, int64_t ldx, const float* w, const float* b, const float* add,
+                     float* out, int64_t ldo, float* out_preact, int M, int K, int O, int act, sdm_stream_t s);
+/* Batched form: njobs projections sharing x (the 16 y_scale GEMVs in one launch). jobs is a DEVICE array. */
+typedef struct sdm_linear_job { const float* w; const float* b; float* out; int O; int pad; } sdm_linear_job;
+int sdm_linear_multi(const float* x, int64_t ldx, int M, int K, const sdm_linear_job* jobs_dev, int njobs,
+                     int maxO, sdm_stream_t s);
+
+/* backward of a small-batch linear given dy (already multiplied by act'):
+ *   dx[m][k] (=|+=) sum_o dy[m][o] w[o][k] ; dw[o][k] += sum_m dy[m][o] x[m][k] ; db[o] += sum_m dy[m][o]
+ * dx / dw may be NULL to skip. */
+int sdm_linear_small_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* w, float* dx,
+                         int64_t lddx, int dx_accumulate, float* dw, float* db, int M, int K, int O, sdm_stream_t s);
+
+/* Generic helpers used by backward. */
+/* out[c] (+)= sum_r x[r][c]  (bias gradients) */
+int sdm_colsum(const float* x, int64_t ldx, int rows, int C, float* out, int accumulate, sdm_stream_t s);
+/* y = silu(x) elementwise (standalone Swish, custom_layers.py:18-20; inside the U-Net it is fused into epilogues) */
+int sdm_silu(const float* x, float* y, size_t n, sdm_stream_t s);
+/* dx = silu'(z) * dy  (elementwise, contiguous n) ; z == NULL -> copy */
+int sdm_silu_bwd(const float* dy, const float* z, float* dx, size_t n, sdm_stream_t s);
+/* y = a + b elementwise */
+int sdm_add(const float* a, const float* b, float* y, size_t n, sdm_stream_t s);
+/* MSE loss of NCHW tensors: loss_out[0] = mean((a-b)^2); grad (may be NULL) = 2(a-b)/n.  F.mse_loss, train_diffusion.py:350 */
+int sdm_mse(const float* a, const float* b, float* loss_out, float* grad, size_t n, sdm_stream_t s);
+/* d tanh: dx = dy * (1 - y^2) */
+int sdm_tanh_bwd(const float* dy, const float* y, float* dx, size_t n, sdm_stream_t s);
+
+/* Forward diffusion q(x_t|x_0) (degraders.py:51-59,96-104): xt = sqrt(ab[n]) x0 + sqrt(1-ab[n]) eps, NCHW. */
+int sdm_q_sample(const float* x0, const float* eps, const float* alpha_bar, float* xt, int images, size_t per_image,
+                 sdm_stream_t s);
+/* DDPM reverse update (diffusion_sampling_algorithms.py:47-55). coef is a DEVICE array of 3 floats
+ * {1/sqrt(alpha_t), (1-alpha_t)/sqrt(1-abar_t), sigma_t} (device-resident so a captured graph can be replayed
+ * with new coefficients); z may be NULL (last step). x is updated in place. */
+int sdm_ddpm_update(float* x, const float* eps, const float* z, const float* coef, size_t n, sdm_stream_t s);
+/* DDIM update (diffusion_sampling_algorithms.py:111-136, eta=0): coef = {1/sqrt(abar_t), sqrt(1-abar_t),
+ * sqrt(abar_tm1), sqrt(1-abar_tm1)}; x0_out optional. */
+int sdm_ddim_update(float* x, const float* eps, const float* coef, float* x0_out, int last, size_t n, sdm_stream_t s);
+
+/* Fused multi-tensor Adam (torch.optim.Adam defaults, train_diffusion.py:214-217): jobs is a DEVICE array. */
+typedef struct sdm_adam_job { float* p; const float* g; float* m; float* v; int64_t n; } sdm_adam_job;
+int sdm_adam_multi(const sdm_adam_job* jobs_dev, int njobs, int64_t max_n, float lr, float beta1, float beta2,
+                   float eps, float bias_c1, float bias_c2, float grad_scale, sdm_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,61 @@
+// Shared device/host helpers for libsdm_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "sdm_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+int sdm_set_error(int code, const char* fmt, ...);
+
+#define SDM_CHECK_ARG(cond, ...)                         \
+  do {                                                   \
+    if (!(cond)) return sdm_set_error(SDM_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+
+#define SDM_CHECK_LAUNCH(name)                                                         \
+  do {                                                                                 \
+    hipError_t e_ = hipGetLastError();                                                 \
+    if (e_ != hipSuccess) return sdm_set_error(SDM_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+#define SDM_MEMSET0(ptr, bytes, st)                                              \
+  do {                                                                           \
+    if (hipMemsetAsync((ptr), 0, (bytes), (st)) != hipSuccess)                   \
+      return sdm_set_error(SDM_ERR_LAUNCH, "hipMemsetAsync failed");             \
+  } while (0)
+
+__device__ __forceinline__ float sdm_sigmoid(float z) { return 1.0f / (1.0f + __expf(-z)); }
+__device__ __forceinline__ float sdm_silu(float z) { return z * sdm_sigmoid(z); }
+__device__ __forceinline__ float sdm_dsilu(float z) {
+  float s = sdm_sigmoid(z);
+  return s * (1.0f + z * (1.0f - s));
+}
+__device__ __forceinline__ float sdm_act(float v, int act) {
+  if (act == SDM_ACT_SILU) return sdm_silu(v);
+  if (act == SDM_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -1,0 +1,597 @@
+// Implicit-GEMM contraction kernels on the gfx950 fp32 matrix cores.
+//
+//   v_mfma_f32_32x32x2_f32:  lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31];
+//   the 32x32 result has col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+//
+// Activations are NHWC "pixel rows x channels", so a conv tap is a shifted row gather with the
+// reduction (channel) dimension contiguous; the weight slice of a tap is a plain [c_out][c_in]
+// matrix.  Both operand tiles go global -> registers (16-byte loads, with the pending
+// GroupNorm/AdaGN affine applied in registers) -> LDS, double-buffered; fragments are read
+// with ds_read_b128 from rows padded to 36 floats (conflict-free) or, for operands whose
+// reduction index is the row index, with ds_read_b32 down the columns (also conflict-free).
+#include "sdm_common.h"
+
+#define BK 32
+#define PITCH 36
+
+struct IgemmLaunch {
+  sdm_igemm_desc d;
+  int splitk, vecA, vecB, ntn, kchunks;
+};
+
+template <int BM, int BN, int WM, int WN, bool BKM>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
+  const sdm_igemm_desc& d = L.d;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int AIT = BM / 32, BIT = BN / 32;
+  constexpr int A_TILE = BM * PITCH;
+  constexpr int B_TILE = BKM ? BK * BN : BN * PITCH;
+  constexpr int CPR = BN / 4;     // K-major B: 16-byte chunks per k-row
+  constexpr int RPP = 256 / CPR;  // rows per pass
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_TILE;
+  long long* s_orow = (long long*)(Bs + 2 * B_TILE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
+  const int tile_n = blockIdx.x % L.ntn, tile_m = blockIdx.x / L.ntn;
+  const int phase = blockIdx.y / L.splitk, ks = blockIdx.y % L.splitk;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
+  const float* a0 = d.a.p0 + b0 * d.a_bs0 + b1 * d.a_bs1;
+  const float* a1 = d.a.p1;
+  const float* bw = d.b + b0 * d.b_bs0 + b1 * d.b_bs1;
+  const int HtWt = d.Ht * d.Wt;
+  const int K = d.K, N = d.N;
+
+  for (int r = tid; r < BM; r += 256) {
+    int m = m0 + r;
+    long long o = -1;
+    if (m < d.M) {
+      int n = m / HtWt, rem = m - n * HtWt;
+      int y = rem / d.Wt, x = rem - y * d.Wt;
+      int oy = y * d.ostride + d.ph_oy[phase], ox = x * d.ostride + d.ph_ox[phase];
+      if (oy < d.Ho && ox < d.Wo) o = ((long long)n * d.Ho + oy) * d.Wo + ox;
+    }
+    s_orow[r] = o;
+  }
+
+  // per-thread A rows: r = (tid>>3) + 32*i, channel chunk = tid&7
+  int a_base[AIT], a_ys[AIT], a_xs[AIT], a_n[AIT];
+#pragma unroll
+  for (int i = 0; i < AIT; ++i) {
+    int m = m0 + (tid >> 3) + 32 * i;
+    if (m < d.M) {
+      int n = m / HtWt, rem = m - n * HtWt;
+      int y = rem / d.Wt, x = rem - y * d.Wt;
+      a_n[i] = n;
+      a_ys[i] = y * d.sstride;
+      a_xs[i] = x * d.sstride;
+      a_base[i] = (n * d.a.H + a_ys[i]) * d.a.W + a_xs[i];
+    } else {
+      a_n[i] = 0; a_ys[i] = -(1 << 20); a_xs[i] = 0; a_base[i] = 0;
+    }
+  }
+
+  const int ntap = d.ntaps[phase];
+  const int kch = L.kchunks;
+  const int T = ntap * kch;
+  const int it0 = (int)((long long)T * ks / L.splitk), it1 = (int)((long long)T * (ks + 1) / L.splitk);
+
+  f32x4 ra[AIT], rb[BIT];
+
+  auto load = [&](int it) {
+    const int tp = it / kch, c0 = (it - tp * kch) * BK;
+    const int dy = d.tap_dy[phase][tp], dx = d.tap_dx[phase][tp];
+    const float* bt = bw + (long long)d.tap_w[phase][tp] * d.b_tap_stride;
+    const int c = c0 + 4 * (tid & 7);
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int sy = a_ys[i] + dy, sx = a_xs[i] + dx;
+      if ((unsigned)sy < (unsigned)d.a.H && (unsigned)sx < (unsigned)d.a.W && c < K) {
+        const long long row = (long long)a_base[i] + dy * d.a.W + dx;
+        const float* p = (c < d.a.csplit) ? a0 + row * d.a.ld0 + c : a1 + row * d.a.ld1 + (c - d.a.csplit);
+        if (L.vecA && c + 3 < K) {
+          v = *(const f32x4*)p;
+        } else {
+          v.x = p[0];
+          if (c + 1 < K) v.y = p[1];
+          if (c + 2 < K) v.z = p[2];
+          if (c + 3 < K) v.w = p[3];
+        }
+        if (d.a.scale) {  // host guarantees K % 4 == 0 here
+          const long long so = (long long)a_n[i] * d.a.aff_nstride + c;
+          const f32x4 sc = *(const f32x4*)(d.a.scale + so);
+          const f32x4 sh = *(const f32x4*)(d.a.shift + so);
+          v = v * sc + sh;
+        }
+      }
+      ra[i] = v;
+    }
+    if (!BKM) {
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int n = n0 + (tid >> 3) + 32 * i;
+        if (n < N && c < K) {
+          const float* p = bt + (long long)n * d.ldb + c;
+          if (L.vecB && c + 3 < K) {
+            v = *(const f32x4*)p;
+          } else {
+            v.x = p[0];
+            if (c + 1 < K) v.y = p[1];
+            if (c + 2 < K) v.z = p[2];
+            if (c + 3 < K) v.w = p[3];
+          }
+        }
+        rb[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int kk = c0 + tid / CPR + RPP * i;
+        const int n = n0 + 4 * (tid % CPR);
+        if (kk < K && n < N) {
+          const float* p = bt + (long long)kk * d.ldb + n;
+          if (L.vecB && n + 3 < N) {
+            v = *(const f32x4*)p;
+          } else {
+            v.x = p[0];
+            if (n + 1 < N) v.y = p[1];
+            if (n + 2 < N) v.z = p[2];
+            if (n + 3 < N) v.w = p[3];
+          }
+        }
+        rb[i] = v;
+      }
+    }
+  };
+
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AIT; ++i)
+      *(f32x4*)&As[buf * A_TILE + ((tid >> 3) + 32 * i) * PITCH + 4 * (tid & 7)] = ra[i];
+    if (!BKM) {
+#pragma unroll
+      for (int i = 0; i < BIT; ++i)
+        *(f32x4*)&Bs[buf * B_TILE + ((tid >> 3) + 32 * i) * PITCH + 4 * (tid & 7)] = rb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < BIT; ++i)
+        *(f32x4*)&Bs[buf * B_TILE + (tid / CPR + RPP * i) * BN + 4 * (tid % CPR)] = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (it0 < it1) {
+    load(it0);
+    store(0);
+  }
+  __syncthreads();
+
+  for (int it = it0; it < it1; ++it) {
+    const int buf = (it - it0) & 1;
+    const bool more = it + 1 < it1;
+    if (more) load(it + 1);
+    const float* Ab = As + buf * A_TILE + (wm * TM * 32 + l31) * PITCH + h * 4;
+    const float* Bb = BKM ? Bs + buf * B_TILE + (h * 4) * BN + wn * TN * 32 + l31
+                          : Bs + buf * B_TILE + (wn * TN * 32 + l31) * PITCH + h * 4;
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(Ab + i * 32 * PITCH + kg * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!BKM) {
+          bf[j] = *(const f32x4*)(Bb + j * 32 * PITCH + kg * 8);
+        } else {
+          bf[j].x = Bb[(kg * 8 + 0) * BN + j * 32];
+          bf[j].y = Bb[(kg * 8 + 1) * BN + j * 32];
+          bf[j].z = Bb[(kg * 8 + 2) * BN + j * 32];
+          bf[j].w = Bb[(kg * 8 + 3) * BN + j * 32];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (more) store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue
+  const long long obo = b0 * d.o_bs0 + b1 * d.o_bs1;
+  const long long rbo = b0 * d.r_bs0 + b1 * d.r_bs1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + l31;
+      if (col >= N) continue;
+      const float bias = d.bias ? d.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long long orow = s_orow[row];
+        if (orow < 0) continue;
+        float v = acc[i][j][r];
+        if (L.splitk > 1) {
+          atomicAdd(&d.ws[orow * N + col], v);
+          continue;
+        }
+        v = v * d.alpha + bias;
+        if (d.out_preact) d.out_preact[obo + orow * d.ldo + col] = v;
+        v = sdm_act(v, d.act);
+        if (d.res) v += d.res[rbo + orow * d.ldres + col];
+        if (d.res2) v += d.res2[orow * d.ldres2 + col];
+        if (d.dact_z && (d.dact_ncols == 0 || col < d.dact_ncols)) v *= sdm_dsilu(d.dact_z[orow * d.ldz + col]);
+        d.out[obo + orow * d.ldo + col] = v;
+      }
+    }
+  }
+}
+
+// Finishes a split-K contraction: ws holds raw sums indexed [out row][N].
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const sdm_igemm_desc d, long long rows) {
+  const long long total = rows * d.N;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long orow = e / d.N;
+    const int col = (int)(e - orow * d.N);
+    float v = d.ws[e] * d.alpha + (d.bias ? d.bias[col] : 0.f);
+    if (d.out_preact) d.out_preact[orow * d.ldo + col] = v;
+    v = sdm_act(v, d.act);
+    if (d.res) v += d.res[orow * d.ldres + col];
+    if (d.res2) v += d.res2[orow * d.ldres2 + col];
+    if (d.dact_z && (d.dact_ncols == 0 || col < d.dact_ncols)) v *= sdm_dsilu(d.dact_z[orow * d.ldz + col]);
+    d.out[orow * d.ldo + col] = v;
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool BKM>
+static int launch_igemm(const IgemmLaunch& L, int ntm, hipStream_t st) {
+  constexpr size_t lds = (2 * BM * PITCH + 2 * (BKM ? BK * BN : BN * PITCH)) * sizeof(float) + BM * sizeof(long long);
+  static bool attr_set = false;
+  auto kern = igemm_kernel<BM, BN, WM, WN, BKM>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(ntm * L.ntn, L.d.nphase * L.splitk, L.d.batch);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, L);
+  SDM_CHECK_LAUNCH("igemm");
+  return SDM_OK;
+}
+
+static int igemm_validate(const sdm_igemm_desc* d) {
+  SDM_CHECK_ARG(d != nullptr, "igemm: null desc");
+  SDM_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "igemm: bad M/N/K %d %d %d", d->M, d->N, d->K);
+  SDM_CHECK_ARG(d->batch >= 1 && d->bdiv >= 1, "igemm: bad batch");
+  SDM_CHECK_ARG(d->a.p0 && d->b && d->out, "igemm: null operand");
+  SDM_CHECK_ARG(d->Ht > 0 && d->Wt > 0 && d->M % (d->Ht * d->Wt) == 0, "igemm: M %d not a multiple of Ht*Wt %d", d->M,
+                d->Ht * d->Wt);
+  SDM_CHECK_ARG(d->nphase >= 1 && d->nphase <= SDM_MAX_PHASE, "igemm: nphase");
+  for (int p = 0; p < d->nphase; ++p) {
+    SDM_CHECK_ARG(d->ntaps[p] >= 1 && d->ntaps[p] <= SDM_MAX_TAPS, "igemm: ntaps");
+  }
+  SDM_CHECK_ARG(d->a.p1 != nullptr || d->a.csplit >= d->K, "igemm: csplit %d < K %d without second source", d->a.csplit,
+                d->K);
+  SDM_CHECK_ARG(d->a.p1 == nullptr || d->a.csplit % 4 == 0, "igemm: concat split must be a multiple of 4");
+  SDM_CHECK_ARG(d->a.scale == nullptr || (d->K % 4 == 0 && d->a.shift != nullptr && aligned16(d->a.scale) &&
+                                          aligned16(d->a.shift) && d->a.aff_nstride % 4 == 0),
+                "igemm: affine-on-load needs K %% 4 == 0 and aligned tables");
+  SDM_CHECK_ARG(d->ostride >= 1 && d->sstride >= 1 && d->Ho > 0 && d->Wo > 0, "igemm: bad strides/output dims");
+  SDM_CHECK_ARG(d->act >= 0 && d->act <= 2, "igemm: bad act");
+  return SDM_OK;
+}
+
+static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* ws_need) {
+  const long M = d->M, N = d->N;
+  const long ph = (long)d->nphase * d->batch;
+  int c;
+  if (M <= 32) c = 2;
+  else if (cdiv(M, 128) * cdiv(N, 128) * ph >= 200 && M >= 128 && N >= 96) c = 0;
+  else c = 1;
+  const int bm = c == 0 ? 128 : (c == 1 ? 64 : 32), bn = c == 1 ? 64 : 128;
+  const long blocks = (long)cdiv(M, bm) * cdiv(N, bn) * ph;
+  int maxtaps = 0;
+  for (int p = 0; p < d->nphase; ++p) maxtaps = d->ntaps[p] > maxtaps ? d->ntaps[p] : maxtaps;
+  const int T = maxtaps * cdiv(d->K, BK);
+  int sk = 1;
+  if (d->batch == 1 && blocks < 192 && T >= 8) {
+    sk = (int)((512 + blocks - 1) / blocks);
+    if (sk > T / 4) sk = T / 4;
+    if (sk > 64) sk = 64;
+    if (sk < 1) sk = 1;
+  }
+  long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
+  *cfg = c;
+  *splitk = sk;
+  *ws_need = sk > 1 ? (size_t)out_rows * N * sizeof(float) : 0;
+}
+
+extern "C" size_t sdm_igemm_workspace_bytes(const sdm_igemm_desc* d) {
+  if (igemm_validate(d) != SDM_OK) return 0;
+  int c, sk;
+  size_t need;
+  igemm_plan(d, &c, &sk, &need);
+  return need;
+}
+
+extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
+  int rc = igemm_validate(d);
+  if (rc != SDM_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  IgemmLaunch L;
+  L.d = *d;
+  int cfg;
+  size_t need;
+  igemm_plan(d, &cfg, &L.splitk, &need);
+  if (L.splitk > 1 && (d->ws == nullptr || d->ws_bytes < need)) L.splitk = 1;  // no scratch: run unsplit
+  L.kchunks = cdiv(d->K, BK);
+  L.vecA = aligned16(d->a.p0) && d->a.ld0 % 4 == 0 && d->a_bs0 % 4 == 0 && d->a_bs1 % 4 == 0 &&
+           (d->a.p1 == nullptr || (aligned16(d->a.p1) && d->a.ld1 % 4 == 0));
+  L.vecB = aligned16(d->b) && d->ldb % 4 == 0 && d->b_tap_stride % 4 == 0 && d->b_bs0 % 4 == 0 && d->b_bs1 % 4 == 0;
+  const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
+  if (L.splitk > 1) {
+    if (hipMemsetAsync(d->ws, 0, need, st) != hipSuccess) return sdm_set_error(SDM_ERR_LAUNCH, "igemm: memset failed");
+  }
+  const int bm = cfg == 0 ? 128 : (cfg == 1 ? 64 : 32), bn = cfg == 1 ? 64 : 128;
+  const int ntm = cdiv(d->M, bm);
+  L.ntn = cdiv(d->N, bn);
+  if (cfg == 0)
+    rc = d->b_kmajor ? launch_igemm<128, 128, 2, 2, true>(L, ntm, st) : launch_igemm<128, 128, 2, 2, false>(L, ntm, st);
+  else if (cfg == 1)
+    rc = d->b_kmajor ? launch_igemm<64, 64, 2, 2, true>(L, ntm, st) : launch_igemm<64, 64, 2, 2, false>(L, ntm, st);
+  else
+    rc = d->b_kmajor ? launch_igemm<32, 128, 1, 4, true>(L, ntm, st) : launch_igemm<32, 128, 1, 4, false>(L, ntm, st);
+  if (rc != SDM_OK) return rc;
+  if (L.splitk > 1) {
+    const long long total = (long long)out_rows * d->N;
+    int grid = (int)((total + 1023) / 1024);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, st, *d, (long long)out_rows);
+    SDM_CHECK_LAUNCH("splitk_epilogue");
+  }
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// weight gradient: dw[tap][i][j] (+)= sum_p G[gpix(p,tap)][i] * X[xpix(p,tap)][j]
+// Both operands are pixel rows with the reduction index on the row: tiles are stored [k][channel]
+// and fragments read down the columns with ds_read_b32.
+// --------------------------------------------------------------------------------------------
+struct WgradLaunch {
+  sdm_wgrad_desc d;
+  int splitk, vecG, vecX, ntn, atomic_out;
+};
+
+template <int BT, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
+  const sdm_wgrad_desc& d = L.d;
+  constexpr int TM = BT / (WM * 32), TN = BT / (WN * 32);
+  constexpr int IT = BT / 32;
+  constexpr int TILE = BK * BT;
+  constexpr int CPR = BT / 4, RPP = 256 / CPR;
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * TILE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
+  const int tile_n = blockIdx.x % L.ntn, tile_m = blockIdx.x / L.ntn;
+  const int tp = blockIdx.y / L.splitk, ks = blockIdx.y % L.splitk;
+  const int m0 = tile_m * BT, n0 = tile_n * BT;
+  const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
+  const float* g0 = d.g.p0 + b0 * d.g_bs0 + b1 * d.g_bs1;
+  const float* x0 = d.x.p0 + b0 * d.x_bs0 + b1 * d.x_bs1;
+  const float* x1 = d.x.p1;
+  const int HW = d.Hk * d.Wk;
+  const long long P = (long long)d.images * HW;
+  const int T = (int)((P + BK - 1) / BK);
+  const int it0 = (int)((long long)T * ks / L.splitk), it1 = (int)((long long)T * (ks + 1) / L.splitk);
+  const int gdy = d.g_dy[tp], gdx = d.g_dx[tp], xdy = d.x_dy[tp], xdx = d.x_dx[tp];
+  const int cm = m0 + 4 * (tid % CPR), cn = n0 + 4 * (tid % CPR);
+
+  f32x4 ra[IT], rb[IT];
+  auto load = [&](int it) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+      const long long p = (long long)it * BK + tid / CPR + RPP * i;
+      if (p < P) {
+        const int n = (int)(p / HW), rem = (int)(p - (long long)n * HW);
+        const int y = rem / d.Wk, x = rem - y * d.Wk;
+        {
+          const int sy = y * d.g_stride + gdy, sx = x * d.g_stride + gdx;
+          if ((unsigned)sy < (unsigned)d.g.H && (unsigned)sx < (unsigned)d.g.W && cm < d.M) {
+            const float* q = g0 + (((long long)n * d.g.H + sy) * d.g.W + sx) * d.g.ld0 + cm;
+            if (L.vecG && cm + 3 < d.M) {
+              va = *(const f32x4*)q;
+            } else {
+              va.x = q[0];
+              if (cm + 1 < d.M) va.y = q[1];
+              if (cm + 2 < d.M) va.z = q[2];
+              if (cm + 3 < d.M) va.w = q[3];
+            }
+          }
+        }
+        {
+          const int sy = y * d.x_stride + xdy, sx = x * d.x_stride + xdx;
+          if ((unsigned)sy < (unsigned)d.x.H && (unsigned)sx < (unsigned)d.x.W && cn < d.N) {
+            const long long row = ((long long)n * d.x.H + sy) * d.x.W + sx;
+            const float* q = (cn < d.x.csplit) ? x0 + row * d.x.ld0 + cn : x1 + row * d.x.ld1 + (cn - d.x.csplit);
+            if (L.vecX && cn + 3 < d.N) {
+              vb = *(const f32x4*)q;
+            } else {
+              vb.x = q[0];
+              if (cn + 1 < d.N) vb.y = q[1];
+              if (cn + 2 < d.N) vb.z = q[2];
+              if (cn + 3 < d.N) vb.w = q[3];
+            }
+            if (d.x.scale) {
+              const long long so = (long long)n * d.x.aff_nstride + cn;
+              const f32x4 sc = *(const f32x4*)(d.x.scale + so);
+              const f32x4 sh = *(const f32x4*)(d.x.shift + so);
+              vb = vb * sc + sh;
+            }
+          }
+        }
+      }
+      ra[i] = va;
+      rb[i] = vb;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int o = buf * TILE + (tid / CPR + RPP * i) * BT + 4 * (tid % CPR);
+      *(f32x4*)&As[o] = ra[i];
+      *(f32x4*)&Bs[o] = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (it0 < it1) {
+    load(it0);
+    store(0);
+  }
+  __syncthreads();
+  for (int it = it0; it < it1; ++it) {
+    const int buf = (it - it0) & 1;
+    const bool more = it + 1 < it1;
+    if (more) load(it + 1);
+    const float* Ab = As + buf * TILE + (h * 4) * BT + wm * TM * 32 + l31;
+    const float* Bb = Bs + buf * TILE + (h * 4) * BT + wn * TN * 32 + l31;
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      float af[TM][4], bf[TN][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i][s] = Ab[(kg * 8 + s) * BT + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j][s] = Bb[(kg * 8 + s) * BT + j * 32];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (more) store(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* dw = d.dw + b0 * d.w_bs0 + b1 * d.w_bs1 + (long long)d.tap_w[tp] * d.w_tap_stride;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + l31;
+      if (col >= d.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= d.M) continue;
+        float* q = dw + (long long)row * d.ldw + col;
+        const float v = acc[i][j][r] * d.alpha;
+        if (L.atomic_out) atomicAdd(q, v);
+        else *q = v;
+      }
+    }
+}
+
+__global__ void zero_rows_kernel(float* p, long long rows, int cols, long long ld) {
+  const long long total = rows * cols;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long r = e / cols;
+    p[r * ld + (e - r * cols)] = 0.f;
+  }
+}
+
+template <int BT, int WM, int WN>
+static int launch_wgrad(const WgradLaunch& L, int ntm, hipStream_t st) {
+  constexpr size_t lds = 4 * BK * BT * sizeof(float);
+  dim3 grid(ntm * L.ntn, L.d.ntaps * L.splitk, L.d.batch);
+  hipLaunchKernelGGL((wgrad_kernel<BT, WM, WN>), grid, dim3(256), lds, st, L);
+  SDM_CHECK_LAUNCH("wgrad");
+  return SDM_OK;
+}
+
+extern "C" int sdm_wgrad(const sdm_wgrad_desc* d, sdm_stream_t stream) {
+  SDM_CHECK_ARG(d != nullptr, "wgrad: null desc");
+  SDM_CHECK_ARG(d->M > 0 && d->N > 0 && d->images > 0 && d->Hk > 0 && d->Wk > 0, "wgrad: bad dims");
+  SDM_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= SDM_MAX_TAPS, "wgrad: ntaps");
+  SDM_CHECK_ARG(d->g.p0 && d->x.p0 && d->dw, "wgrad: null operand");
+  SDM_CHECK_ARG(d->batch >= 1 && d->bdiv >= 1, "wgrad: bad batch");
+  SDM_CHECK_ARG(d->g.p1 == nullptr && d->g.scale == nullptr, "wgrad: gradient rows cannot be concat/affine");
+  SDM_CHECK_ARG(d->x.p1 != nullptr || d->x.csplit >= d->N, "wgrad: csplit < N without second source");
+  SDM_CHECK_ARG(d->x.p1 == nullptr || d->x.csplit % 4 == 0, "wgrad: concat split must be a multiple of 4");
+  SDM_CHECK_ARG(d->x.scale == nullptr || (d->N % 4 == 0 && d->x.shift && aligned16(d->x.scale) && aligned16(d->x.shift) &&
+                                          d->x.aff_nstride % 4 == 0),
+                "wgrad: affine-on-load needs N %% 4 == 0 and aligned tables");
+  hipStream_t st = (hipStream_t)stream;
+  WgradLaunch L;
+  L.d = *d;
+  const long P = (long)d->images * d->Hk * d->Wk;
+  const int T = cdiv(P, BK);
+  const bool big = d->M >= 128 && d->N >= 128;
+  const int bt = big ? 128 : 64;
+  const int ntm = cdiv(d->M, bt);
+  L.ntn = cdiv(d->N, bt);
+  const long blocks = (long)ntm * L.ntn * d->ntaps * d->batch;
+  int sk = 1;
+  if (blocks < 384 && T >= 8) {
+    sk = (int)((768 + blocks - 1) / blocks);
+    if (sk > T / 4) sk = T / 4;
+    if (sk > 128) sk = 128;
+    if (sk < 1) sk = 1;
+  }
+  L.splitk = sk;
+  L.atomic_out = (sk > 1 || d->accumulate) ? 1 : 0;
+  L.vecG = aligned16(d->g.p0) && d->g.ld0 % 4 == 0 && d->g_bs0 % 4 == 0 && d->g_bs1 % 4 == 0;
+  L.vecX = aligned16(d->x.p0) && d->x.ld0 % 4 == 0 && d->x_bs0 % 4 == 0 && d->x_bs1 % 4 == 0 &&
+           (d->x.p1 == nullptr || (aligned16(d->x.p1) && d->x.ld1 % 4 == 0));
+  if (sk > 1 && !d->accumulate) {
+    for (int b = 0; b < d->batch; ++b) {
+      for (int t = 0; t < d->ntaps; ++t) {
+        float* p = d->dw + (b / d->bdiv) * d->w_bs0 + (b % d->bdiv) * d->w_bs1 + (long long)d->tap_w[t] * d->w_tap_stride;
+        if (d->ldw == d->N) {
+          if (hipMemsetAsync(p, 0, (size_t)d->M * d->N * sizeof(float), st) != hipSuccess)
+            return sdm_set_error(SDM_ERR_LAUNCH, "wgrad: memset failed");
+        } else {
+          hipLaunchKernelGGL(zero_rows_kernel, dim3(cdiv((long)d->M * d->N, 1024)), dim3(256), 0, st, p, (long long)d->M,
+                             d->N, (long long)d->ldw);
+          SDM_CHECK_LAUNCH("zero_rows");
+        }
+      }
+    }
+  }
+  if (big) return launch_wgrad<128, 2, 2>(L, ntm, st);
+  return launch_wgrad<64, 2, 2>(L, ntm, st);
+}

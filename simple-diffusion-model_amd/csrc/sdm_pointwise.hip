@@ -1,0 +1,861 @@
+// Bandwidth-bound kernels of the U-Net step: NCHW<->NHWC edge convs, GroupNorm/AdaGN folding,
+// column softmax, embedding MLP GEMVs, sampler updates, loss, fused Adam.  All wave64.
+#include "sdm_common.h"
+
+// --------------------------------------------------------------------------------------------
+// stem: Conv2d(Cin<=8 -> C) k3 p1, NCHW image in, NHWC rows out (+SiLU)
+// block = 256 threads over output channels; PIX pixels per block share their input patches via LDS
+// --------------------------------------------------------------------------------------------
+#define STEM_PIX 32
+#define EDGE_MAXC 8
+
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        float* __restrict__ preact, int images, int Cin, int H, int W,
+                                                        int Cout, int act) {
+  __shared__ float patch[STEM_PIX][EDGE_MAXC * 9];
+  const long long P = (long long)images * H * W;
+  const long long p0 = (long long)blockIdx.x * STEM_PIX;
+  const int K = Cin * 9;
+  for (int e = threadIdx.x; e < STEM_PIX * K; e += 256) {
+    const int pi = e / K, k = e - pi * K;
+    const int ci = k / 9, tap = k - ci * 9;
+    const long long p = p0 + pi;
+    float v = 0.f;
+    if (p < P) {
+      const int n = (int)(p / (H * W)), rem = (int)(p - (long long)n * H * W);
+      const int y = rem / W + tap / 3 - 1, xx = rem % W + tap % 3 - 1;
+      if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = x[(((long long)n * Cin + ci) * H + y) * W + xx];
+    }
+    patch[pi][k] = v;
+  }
+  __syncthreads();
+  for (int co = threadIdx.x; co < Cout; co += 256) {
+    float wr[EDGE_MAXC * 9];
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int tap = 0; tap < 9; ++tap) wr[ci * 9 + tap] = w[((long long)tap * Cout + co) * Cin + ci];
+    const float b = bias ? bias[co] : 0.f;
+    for (int pi = 0; pi < STEM_PIX; ++pi) {
+      const long long p = p0 + pi;
+      if (p >= P) break;
+      float a = b;
+      for (int k = 0; k < K; ++k) a = fmaf(patch[pi][k], wr[k], a);
+      if (preact) preact[p * Cout + co] = a;
+      out[p * Cout + co] = sdm_act(a, act);
+    }
+  }
+}
+
+extern "C" int sdm_stem_conv(const float* x, const float* w, const float* bias, float* out, float* preact, int images,
+                             int Cin, int H, int W, int Cout, int act, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && w && out && images > 0 && H > 0 && W > 0 && Cout > 0, "stem_conv: bad args");
+  SDM_CHECK_ARG(Cin >= 1 && Cin <= EDGE_MAXC, "stem_conv: Cin %d not in [1,%d]", Cin, EDGE_MAXC);
+  const long long P = (long long)images * H * W;
+  hipLaunchKernelGGL(stem_conv_kernel, dim3(cdiv(P, STEM_PIX)), dim3(256), 0, (hipStream_t)s, x, w, bias, out, preact,
+                     images, Cin, H, W, Cout, act);
+  SDM_CHECK_LAUNCH("stem_conv");
+  return SDM_OK;
+}
+
+// stem weight/bias gradient: dw[tap][co][ci] = sum_p g[p][co] * x[n][ci][p+d(tap)] ; db[co] = sum_p g[p][co]
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         float* __restrict__ dw, float* __restrict__ db, int images,
+                                                         int Cin, int H, int W, int Cout, int pix_per_block) {
+  __shared__ float patch[STEM_PIX][EDGE_MAXC * 9];
+  const long long P = (long long)images * H * W;
+  const int K = Cin * 9;
+  const int co = threadIdx.x;  // Cout <= 256 per pass handled by loop below
+  float acc[EDGE_MAXC * 9];
+  float accb = 0.f;
+  for (int cb = 0; cb < Cout; cb += 256) {
+    for (int k = 0; k < EDGE_MAXC * 9; ++k) acc[k] = 0.f;
+    accb = 0.f;
+    const long long pb = (long long)blockIdx.x * pix_per_block;
+    for (int q = 0; q < pix_per_block; q += STEM_PIX) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < STEM_PIX * K; e += 256) {
+        const int pi = e / K, k = e - pi * K;
+        const int ci = k / 9, tap = k - ci * 9;
+        const long long p = pb + q + pi;
+        float v = 0.f;
+        if (p < P && q + pi < pix_per_block) {
+          const int n = (int)(p / (H * W)), rem = (int)(p - (long long)n * H * W);
+          const int y = rem / W + tap / 3 - 1, xx = rem % W + tap % 3 - 1;
+          if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = x[(((long long)n * Cin + ci) * H + y) * W + xx];
+        }
+        patch[pi][k] = v;
+      }
+      __syncthreads();
+      if (cb + co < Cout) {
+        for (int pi = 0; pi < STEM_PIX; ++pi) {
+          const long long p = pb + q + pi;
+          if (p >= P || q + pi >= pix_per_block) break;
+          const float gv = g[p * Cout + cb + co];
+          accb += gv;
+          for (int k = 0; k < K; ++k) acc[k] = fmaf(gv, patch[pi][k], acc[k]);
+        }
+      }
+    }
+    if (cb + co < Cout) {
+      for (int ci = 0; ci < Cin; ++ci)
+        for (int tap = 0; tap < 9; ++tap) atomicAdd(&dw[((long long)tap * Cout + cb + co) * Cin + ci], acc[ci * 9 + tap]);
+      if (db) atomicAdd(&db[cb + co], accb);
+    }
+  }
+}
+
+extern "C" int sdm_stem_conv_wgrad(const float* x, const float* g, float* dw, float* db, int images, int Cin, int H, int W,
+                                   int Cout, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && g && dw && Cin >= 1 && Cin <= EDGE_MAXC, "stem_conv_wgrad: bad args");
+  hipStream_t st = (hipStream_t)s;
+  const long long P = (long long)images * H * W;
+  SDM_MEMSET0(dw, (size_t)9 * Cout * Cin * sizeof(float), st);
+  if (db) SDM_MEMSET0(db, (size_t)Cout * sizeof(float), st);
+  int ppb = (int)((P + 511) / 512);
+  ppb = ((ppb + STEM_PIX - 1) / STEM_PIX) * STEM_PIX;
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(cdiv(P, ppb)), dim3(256), 0, st, x, g, dw, db, images, Cin, H, W, Cout, ppb);
+  SDM_CHECK_LAUNCH("stem_conv_wgrad");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// head: Conv2d(C -> Cout<=8) k3 p1, NHWC rows in, NCHW out (+Tanh).  One wave per output pixel.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        int images, int Cin, int H, int W, int Cout, int act) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long P = (long long)images * H * W;
+  for (long long p = (long long)blockIdx.x * 4 + wave; p < P; p += (long long)gridDim.x * 4) {
+    const int n = (int)(p / (H * W)), rem = (int)(p - (long long)n * H * W);
+    const int y = rem / W, xx = rem % W;
+    float acc[EDGE_MAXC];
+    for (int co = 0; co < EDGE_MAXC; ++co) acc[co] = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int sy = y + tap / 3 - 1, sx = xx + tap % 3 - 1;
+      if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) continue;
+      const float* xr = x + (((long long)n * H + sy) * W + sx) * Cin;
+      for (int c = lane; c < Cin; c += 64) {
+        const float xv = xr[c];
+        for (int co = 0; co < Cout; ++co) acc[co] = fmaf(xv, w[((long long)tap * Cout + co) * Cin + c], acc[co]);
+      }
+    }
+    for (int co = 0; co < Cout; ++co) {
+      const float v = wave_sum(acc[co]);
+      if (lane == co) out[(((long long)n * Cout + co) * H + y) * W + xx] = sdm_act(v + (bias ? bias[co] : 0.f), act);
+    }
+  }
+}
+
+extern "C" int sdm_head_conv(const float* x, const float* w, const float* bias, float* out, int images, int Cin, int H,
+                             int W, int Cout, int act, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && w && out && images > 0 && H > 0 && W > 0 && Cin > 0, "head_conv: bad args");
+  SDM_CHECK_ARG(Cout >= 1 && Cout <= EDGE_MAXC, "head_conv: Cout %d not in [1,%d]", Cout, EDGE_MAXC);
+  const long long P = (long long)images * H * W;
+  int grid = (int)((P + 3) / 4);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(head_conv_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, x, w, bias, out, images, Cin, H, W, Cout,
+                     act);
+  SDM_CHECK_LAUNCH("head_conv");
+  return SDM_OK;
+}
+
+// dx[p][c] = silu'(z[p][c]) * sum_tap sum_co dy[n][co][p - d(tap)] * w[tap][co][c]
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                         float* __restrict__ dx, const float* __restrict__ z, int images,
+                                                         int Cin, int H, int W, int Cout) {
+  __shared__ float g[4][9 * EDGE_MAXC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long P = (long long)images * H * W;
+  for (long long pb = (long long)blockIdx.x * 4; pb < P; pb += (long long)gridDim.x * 4) {
+    const long long p = pb + wave;
+    __syncthreads();
+    if (p < P) {
+      const int n = (int)(p / (H * W)), rem = (int)(p - (long long)n * H * W);
+      const int y = rem / W, xx = rem % W;
+      for (int e = lane; e < 9 * Cout; e += 64) {
+        const int tap = e / Cout, co = e - tap * Cout;
+        const int sy = y - (tap / 3 - 1), sx = xx - (tap % 3 - 1);
+        float v = 0.f;
+        if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) v = dy[(((long long)n * Cout + co) * H + sy) * W + sx];
+        g[wave][e] = v;
+      }
+    }
+    __syncthreads();
+    if (p < P) {
+      for (int c = lane; c < Cin; c += 64) {
+        float a = 0.f;
+        for (int e = 0; e < 9 * Cout; ++e) a = fmaf(g[wave][e], w[(long long)e * Cin + c], a);
+        if (z) a *= sdm_dsilu(z[p * Cin + c]);
+        dx[p * Cin + c] = a;
+      }
+    }
+  }
+}
+
+extern "C" int sdm_head_conv_dgrad(const float* dy, const float* w, float* dx, const float* z, int images, int Cin, int H,
+                                   int W, int Cout, sdm_stream_t s) {
+  SDM_CHECK_ARG(dy && w && dx && Cout >= 1 && Cout <= EDGE_MAXC, "head_conv_dgrad: bad args");
+  const long long P = (long long)images * H * W;
+  int grid = (int)((P + 3) / 4);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(head_dgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, dy, w, dx, z, images, Cin, H, W, Cout);
+  SDM_CHECK_LAUNCH("head_conv_dgrad");
+  return SDM_OK;
+}
+
+// dw[tap][co][c] = sum_p g[n][co][p] * x[p + d(tap)][c]; threads over c, Cout*9 accumulators each
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         float* __restrict__ dw, float* __restrict__ db, int images,
+                                                         int Cin, int H, int W, int Cout, int pix_per_block) {
+  const long long P = (long long)images * H * W;
+  const long long pb = (long long)blockIdx.x * pix_per_block;
+  for (int c = threadIdx.x; c < Cin; c += 256) {
+    float acc[9 * EDGE_MAXC];
+    for (int k = 0; k < 9 * EDGE_MAXC; ++k) acc[k] = 0.f;
+    for (int q = 0; q < pix_per_block; ++q) {
+      const long long p = pb + q;
+      if (p >= P) break;
+      const int n = (int)(p / (H * W)), rem = (int)(p - (long long)n * H * W);
+      const int y = rem / W, xx = rem % W;
+      float gv[EDGE_MAXC];
+      for (int co = 0; co < Cout; ++co) gv[co] = g[(((long long)n * Cout + co) * H + y) * W + xx];
+      for (int tap = 0; tap < 9; ++tap) {
+        const int sy = y + tap / 3 - 1, sx = xx + tap % 3 - 1;
+        if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) continue;
+        const float xv = x[(((long long)n * H + sy) * W + sx) * Cin + c];
+        for (int co = 0; co < Cout; ++co) acc[tap * EDGE_MAXC + co] = fmaf(gv[co], xv, acc[tap * EDGE_MAXC + co]);
+      }
+    }
+    for (int tap = 0; tap < 9; ++tap)
+      for (int co = 0; co < Cout; ++co) atomicAdd(&dw[((long long)tap * Cout + co) * Cin + c], acc[tap * EDGE_MAXC + co]);
+  }
+  if (db && threadIdx.x < Cout) {
+    float a = 0.f;
+    for (int q = 0; q < pix_per_block; ++q) {
+      const long long p = pb + q;
+      if (p >= P) break;
+      const int n = (int)(p / (H * W)), rem = (int)(p - (long long)n * H * W);
+      a += g[((long long)n * Cout + threadIdx.x) * H * W + rem];
+    }
+    atomicAdd(&db[threadIdx.x], a);
+  }
+}
+
+extern "C" int sdm_head_conv_wgrad(const float* x, const float* g, float* dw, float* db, int images, int Cin, int H, int W,
+                                   int Cout, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && g && dw && Cout >= 1 && Cout <= EDGE_MAXC, "head_conv_wgrad: bad args");
+  hipStream_t st = (hipStream_t)s;
+  const long long P = (long long)images * H * W;
+  SDM_MEMSET0(dw, (size_t)9 * Cout * Cin * sizeof(float), st);
+  if (db) SDM_MEMSET0(db, (size_t)Cout * sizeof(float), st);
+  int ppb = (int)((P + 1023) / 1024);
+  if (ppb < 1) ppb = 1;
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3(cdiv(P, ppb)), dim3(256), 0, st, x, g, dw, db, images, Cin, H, W, Cout, ppb);
+  SDM_CHECK_LAUNCH("head_conv_wgrad");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// GroupNorm statistics folded with the AdaGN modulation -> per-(image,channel) affine
+// one block per (image, group); fp64 accumulation
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_affine_kernel(const float* __restrict__ y, long long ldy, int HW, int C,
+                                                        int groups, float eps, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ mod,
+                                                        int mod_ns, float* __restrict__ scale, float* __restrict__ shift,
+                                                        float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+  __shared__ double red[2][4];
+  const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cpg = C / groups;
+  const float* base = y + (long long)n * HW * ldy + g * cpg;
+  double s1 = 0.0, s2 = 0.0;
+  const long long total = (long long)HW * cpg;
+  for (long long e = threadIdx.x; e < total; e += 256) {
+    const long long pix = e / cpg;
+    const int c = (int)(e - pix * cpg);
+    const double v = base[pix * ldy + c];
+    s1 += v;
+    s2 += v * v;
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+  __syncthreads();
+  s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const double mean = s1 / (double)total;
+  double var = s2 / (double)total - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float mu = (float)mean;
+  if (threadIdx.x == 0) {
+    mean_o[n * groups + g] = mu;
+    rstd_o[n * groups + g] = rstd;
+  }
+  for (int c = threadIdx.x; c < cpg; c += 256) {
+    const int ch = g * cpg + c;
+    const float ga = gamma[ch], be = beta[ch];
+    const float sm = mod ? mod[(long long)n * mod_ns + ch] : 1.f;
+    const float a = rstd * ga * sm;
+    const float b = mod ? (be - mu * rstd * ga) * sm + sm : (be - mu * rstd * ga);
+    scale[(long long)n * C + ch] = a;
+    shift[(long long)n * C + ch] = b;
+  }
+}
+
+extern "C" int sdm_gn_affine(const float* y, int64_t ldy, int images, int HW, int C, int groups, float eps,
+                             const float* gamma, const float* beta, const float* mod, int mod_nstride, float* scale,
+                             float* shift, float* mean, float* rstd, sdm_stream_t s) {
+  SDM_CHECK_ARG(y && gamma && beta && scale && shift && mean && rstd, "gn_affine: null pointer");
+  SDM_CHECK_ARG(images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_affine: C %d not divisible by groups %d", C,
+                groups);
+  hipLaunchKernelGGL(gn_affine_kernel, dim3(images * groups), dim3(256), 0, (hipStream_t)s, y, (long long)ldy, HW, C,
+                     groups, eps, gamma, beta, mod, mod_nstride, scale, shift, mean, rstd);
+  SDM_CHECK_LAUNCH("gn_affine");
+  return SDM_OK;
+}
+
+// out = scale*y + shift + cat(x0,x1)
+__global__ __launch_bounds__(256) void affine_residual_kernel(const float* __restrict__ y, long long ldy,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int ans,
+                                                              const float* __restrict__ x0, long long ldx0,
+                                                              const float* __restrict__ x1, long long ldx1, int csplit,
+                                                              float* __restrict__ out, long long ldo, long long rows,
+                                                              int HW, int C, int vec) {
+  if (vec) {
+    const int C4 = C >> 2;
+    const long long total = rows * C4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+      const long long r = e / C4;
+      const int c = (int)(e - r * C4) * 4;
+      const int n = (int)(r / HW);
+      f32x4 v = *(const f32x4*)(y + r * ldy + c);
+      if (scale) {
+        const f32x4 a = *(const f32x4*)(scale + (long long)n * ans + c);
+        const f32x4 b = *(const f32x4*)(shift + (long long)n * ans + c);
+        v = v * a + b;
+      }
+      const f32x4 xv = (c < csplit) ? *(const f32x4*)(x0 + r * ldx0 + c) : *(const f32x4*)(x1 + r * ldx1 + (c - csplit));
+      *(f32x4*)(out + r * ldo + c) = v + xv;
+    }
+  } else {
+    const long long total = rows * C;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+      const long long r = e / C;
+      const int c = (int)(e - r * C);
+      const int n = (int)(r / HW);
+      float v = y[r * ldy + c];
+      if (scale) v = v * scale[(long long)n * ans + c] + shift[(long long)n * ans + c];
+      v += (c < csplit) ? x0[r * ldx0 + c] : x1[r * ldx1 + (c - csplit)];
+      out[r * ldo + c] = v;
+    }
+  }
+}
+
+extern "C" int sdm_affine_residual(const float* y, int64_t ldy, const float* scale, const float* shift, int aff_nstride,
+                                   const float* x0, int64_t ldx0, const float* x1, int64_t ldx1, int csplit, float* out,
+                                   int64_t ldo, int images, int HW, int C, sdm_stream_t s) {
+  SDM_CHECK_ARG(y && x0 && out && images > 0 && HW > 0 && C > 0, "affine_residual: bad args");
+  SDM_CHECK_ARG(x1 != nullptr || csplit >= C, "affine_residual: csplit < C without second source");
+  const long long rows = (long long)images * HW;
+  const int vec = (C % 4 == 0) && (csplit % 4 == 0) && ldy % 4 == 0 && ldx0 % 4 == 0 && (x1 == nullptr || ldx1 % 4 == 0) &&
+                  ldo % 4 == 0 && aff_nstride % 4 == 0 && aligned16(y) && aligned16(x0) && aligned16(out) &&
+                  (x1 == nullptr || aligned16(x1)) && (scale == nullptr || (aligned16(scale) && aligned16(shift)));
+  long long work = rows * (vec ? C / 4 : C);
+  int grid = (int)((work + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(affine_residual_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, y, (long long)ldy, scale, shift,
+                     aff_nstride, x0, (long long)ldx0, x1, (long long)ldx1, csplit, out, (long long)ldo, rows, HW, C, vec);
+  SDM_CHECK_LAUNCH("affine_residual");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// AdaGN backward (see header).  ws: [images][C][2] = (sum dout, sum dout*y)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const float* __restrict__ dout, long long lddo,
+                                                          const float* __restrict__ y, long long ldy, int HW, int C,
+                                                          int rows_per_block, float* __restrict__ ws) {
+  const int n = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > HW) r1 = HW;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      const long long row = (long long)n * HW + r;
+      const float d = dout[row * lddo + c];
+      s1 += d;
+      s2 = fmaf(d, y[row * ldy + c], s2);
+    }
+    atomicAdd(&ws[((long long)n * C + c) * 2 + 0], s1);
+    atomicAdd(&ws[((long long)n * C + c) * 2 + 1], s2);
+  }
+}
+
+// one block per (image, group): turns the sums into per-channel coefficients (k1,k2,k3) stored back into ws-like
+// coef[n][C][3], and emits dmod / dgamma / dbeta.
+__global__ __launch_bounds__(64) void gn_bwd_coef_kernel(const float* __restrict__ ws, int HW, int C, int groups,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ mod, int mod_ns,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float* __restrict__ coef, float* __restrict__ dmod,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cpg = C / groups;
+  const float mu = mean[n * groups + g], rs = rstd[n * groups + g];
+  float A = 0.f, B = 0.f;
+  for (int c = threadIdx.x; c < cpg; c += 64) {
+    const int ch = g * cpg + c;
+    const float S1 = ws[((long long)n * C + ch) * 2], S2 = ws[((long long)n * C + ch) * 2 + 1];
+    const float sm = mod ? mod[(long long)n * mod_ns + ch] : 1.f;
+    const float sg = sm * gamma[ch];
+    A += sg * S1;
+    B += sg * rs * (S2 - mu * S1);
+  }
+  A = wave_sum(A);
+  B = wave_sum(B);
+  const float cnt = (float)HW * (float)cpg;
+  A /= cnt;
+  B /= cnt;
+  for (int c = threadIdx.x; c < cpg; c += 64) {
+    const int ch = g * cpg + c;
+    const float S1 = ws[((long long)n * C + ch) * 2], S2 = ws[((long long)n * C + ch) * 2 + 1];
+    const float sm = mod ? mod[(long long)n * mod_ns + ch] : 1.f;
+    const float ga = gamma[ch], be = beta[ch];
+    const float xh = rs * (S2 - mu * S1);  // sum dout * xhat
+    float* k = coef + ((long long)n * C + ch) * 3;
+    k[0] = rs * sm * ga;
+    k[1] = -rs * rs * B;
+    k[2] = -rs * A + mu * rs * rs * B;
+    if (dmod) dmod[(long long)n * C + ch] = ga * xh + (mod ? (be + 1.f) : be) * S1;
+    if (dgamma) atomicAdd(&dgamma[ch], sm * xh);
+    if (dbeta) atomicAdd(&dbeta[ch], sm * S1);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dout, long long lddo,
+                                                           const float* __restrict__ y, long long ldy,
+                                                           const float* __restrict__ z, long long ldz,
+                                                           const float* __restrict__ coef, float* __restrict__ dz,
+                                                           long long lddz, long long rows, int HW, int C) {
+  const long long total = rows * C;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long r = e / C;
+    const int c = (int)(e - r * C);
+    const int n = (int)(r / HW);
+    const float* k = coef + ((long long)n * C + c) * 3;
+    float v = k[0] * dout[r * lddo + c] + k[1] * y[r * ldy + c] + k[2];
+    if (z) v *= sdm_dsilu(z[r * ldz + c]);
+    dz[r * lddz + c] = v;
+  }
+}
+
+extern "C" int sdm_gn_adagn_bwd(const float* dout, int64_t lddo, const float* y, int64_t ldy, const float* z, int64_t ldz,
+                                int images, int HW, int C, int groups, const float* gamma, const float* beta,
+                                const float* mod, int mod_nstride, const float* mean, const float* rstd, float* dz,
+                                int64_t lddz, float* dmod, float* dgamma, float* dbeta, float* ws, sdm_stream_t s) {
+  SDM_CHECK_ARG(dout && y && gamma && beta && mean && rstd && dz && ws, "gn_adagn_bwd: null pointer");
+  SDM_CHECK_ARG(images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_adagn_bwd: bad dims");
+  hipStream_t st = (hipStream_t)s;
+  float* coef = ws + (size_t)images * C * 2;  // caller provides images*C*5 floats
+  SDM_MEMSET0(ws, (size_t)images * C * 2 * sizeof(float), st);
+  int rpb = (HW + 63) / 64;
+  if (rpb < 8) rpb = 8;
+  hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(cdiv(HW, rpb), images), dim3(256), 0, st, dout, (long long)lddo, y,
+                     (long long)ldy, HW, C, rpb, ws);
+  SDM_CHECK_LAUNCH("gn_bwd_sums");
+  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(images * groups), dim3(64), 0, st, ws, HW, C, groups, gamma, beta, mod,
+                     mod_nstride, mean, rstd, coef, dmod, dgamma, dbeta);
+  SDM_CHECK_LAUNCH("gn_bwd_coef");
+  const long long rows = (long long)images * HW;
+  int grid = (int)((rows * C + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, dout, (long long)lddo, y, (long long)ldy, z,
+                     (long long)ldz, coef, dz, (long long)lddz, rows, HW, C);
+  SDM_CHECK_LAUNCH("gn_bwd_apply");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// column softmax: normalise over rows i for every column j.  Block = 64 columns x 4 row-phases.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void col_softmax_kernel(float* __restrict__ sc, int S, long long lds) {
+  __shared__ float sm[4][64], ss[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  float* base = sc + (long long)blockIdx.y * S * lds;
+  float m = -INFINITY, l = 0.f;
+  if (j < S) {
+    for (int i = wave; i < S; i += 4) {
+      const float v = base[(long long)i * lds + j];
+      if (v > m) {
+        l = l * __expf(m - v) + 1.f;
+        m = v;
+      } else {
+        l += __expf(v - m);
+      }
+    }
+  }
+  sm[wave][lane] = m;
+  ss[wave][lane] = l;
+  __syncthreads();
+  float M = fmaxf(fmaxf(sm[0][lane], sm[1][lane]), fmaxf(sm[2][lane], sm[3][lane]));
+  float Lsum = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+    if (ss[w][lane] > 0.f) Lsum += ss[w][lane] * __expf(sm[w][lane] - M);
+  if (j < S) {
+    const float inv = 1.f / Lsum;
+    for (int i = wave; i < S; i += 4) {
+      float* p = base + (long long)i * lds + j;
+      *p = __expf(*p - M) * inv;
+    }
+  }
+}
+
+extern "C" int sdm_col_softmax(float* scores, int batch, int S, int64_t lds, sdm_stream_t s) {
+  SDM_CHECK_ARG(scores && batch > 0 && S > 0 && lds >= S, "col_softmax: bad args");
+  hipLaunchKernelGGL(col_softmax_kernel, dim3(cdiv(S, 64), batch), dim3(256), 0, (hipStream_t)s, scores, S, (long long)lds);
+  SDM_CHECK_LAUNCH("col_softmax");
+  return SDM_OK;
+}
+
+__global__ __launch_bounds__(256) void col_softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, int S,
+                                                              long long lds, float scale) {
+  __shared__ float sd[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const long long bo = (long long)blockIdx.y * S * lds;
+  float dot = 0.f;
+  if (j < S)
+    for (int i = wave; i < S; i += 4) dot = fmaf(p[bo + (long long)i * lds + j], dp[bo + (long long)i * lds + j], dot);
+  sd[wave][lane] = dot;
+  __syncthreads();
+  dot = sd[0][lane] + sd[1][lane] + sd[2][lane] + sd[3][lane];
+  if (j < S)
+    for (int i = wave; i < S; i += 4) {
+      const long long o = bo + (long long)i * lds + j;
+      dp[o] = scale * p[o] * (dp[o] - dot);
+    }
+}
+
+extern "C" int sdm_col_softmax_bwd(const float* p, float* dp, int batch, int S, int64_t lds, float scale, sdm_stream_t s) {
+  SDM_CHECK_ARG(p && dp && batch > 0 && S > 0 && lds >= S, "col_softmax_bwd: bad args");
+  hipLaunchKernelGGL(col_softmax_bwd_kernel, dim3(cdiv(S, 64), batch), dim3(256), 0, (hipStream_t)s, p, dp, S,
+                     (long long)lds, scale);
+  SDM_CHECK_LAUNCH("col_softmax_bwd");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// embedding: sinusoid features and small-batch linears
+// --------------------------------------------------------------------------------------------
+__global__ void sinusoid_kernel(const int64_t* __restrict__ t, const float* __restrict__ freq, int n, int D,
+                                float* __restrict__ out) {
+  const int half = D / 2;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * half) return;
+  const int r = e / half, i = e - r * half;
+  const float a = (float)t[r] * freq[i];
+  out[(long long)r * D + i] = sinf(a);
+  out[(long long)r * D + half + i] = cosf(a);
+}
+
+// freq table is host-computed exactly as the reference does (torch.exp(arange(half) * -ln(1e4)/(half-1))).
+extern "C" int sdm_sinusoid(const int64_t* t, const float* freq, int n, int D, float* out, sdm_stream_t s) {
+  SDM_CHECK_ARG(t && freq && out && n > 0 && D >= 2 && D % 2 == 0, "sinusoid: bad args");
+  const int total = n * (D / 2);
+  hipLaunchKernelGGL(sinusoid_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)s, t, freq, n, D, out);
+  SDM_CHECK_LAUNCH("sinusoid");
+  return SDM_OK;
+}
+
+#define LS_MT 8
+// one wave per output feature; x rows streamed LS_MT at a time
+__device__ __forceinline__ void linear_small_body(const float* __restrict__ x, long long ldx, const float* __restrict__ w,
+                                                  const float* __restrict__ b, const float* __restrict__ add,
+                                                  float* __restrict__ out, long long ldo, float* __restrict__ preact,
+                                                  int M, int K, int O, int act, int o, int lane) {
+  if (o >= O) return;
+  const float* wr = w + (long long)o * K;
+  for (int m0 = 0; m0 < M; m0 += LS_MT) {
+    float acc[LS_MT];
+#pragma unroll
+    for (int i = 0; i < LS_MT; ++i) acc[i] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float wv = wr[k];
+#pragma unroll
+      for (int i = 0; i < LS_MT; ++i)
+        if (m0 + i < M) acc[i] = fmaf(x[(long long)(m0 + i) * ldx + k], wv, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < LS_MT; ++i) {
+      const float v = wave_sum(acc[i]);
+      if (lane == 0 && m0 + i < M) {
+        float r = v + (b ? b[o] : 0.f);
+        if (preact) preact[(long long)(m0 + i) * ldo + o] = r;
+        r = sdm_act(r, act);
+        if (add) r += add[(long long)(m0 + i) * ldo + o];
+        out[(long long)(m0 + i) * ldo + o] = r;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* x, long long ldx, const float* w, const float* b,
+                                                           const float* add, float* out, long long ldo, float* preact,
+                                                           int M, int K, int O, int act) {
+  linear_small_body(x, ldx, w, b, add, out, ldo, preact, M, K, O, act, blockIdx.x * 4 + (threadIdx.x >> 6),
+                    threadIdx.x & 63);
+}
+
+extern "C" int sdm_linear_small(const float* x, int64_t ldx, const float* w, const float* b, const float* add, float* out,
+                                int64_t ldo, float* out_preact, int M, int K, int O, int act, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && w && out && M > 0 && K > 0 && O > 0, "linear_small: bad args");
+  hipLaunchKernelGGL(linear_small_kernel, dim3(cdiv(O, 4)), dim3(256), 0, (hipStream_t)s, x, (long long)ldx, w, b, add, out,
+                     (long long)ldo, out_preact, M, K, O, act);
+  SDM_CHECK_LAUNCH("linear_small");
+  return SDM_OK;
+}
+
+__global__ __launch_bounds__(256) void linear_multi_kernel(const float* x, long long ldx, int M, int K,
+                                                           const sdm_linear_job* jobs) {
+  const sdm_linear_job j = jobs[blockIdx.y];
+  linear_small_body(x, ldx, j.w, j.b, nullptr, j.out, (long long)j.O, nullptr, M, K, j.O, SDM_ACT_NONE,
+                    blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+extern "C" int sdm_linear_multi(const float* x, int64_t ldx, int M, int K, const sdm_linear_job* jobs_dev, int njobs,
+                                int maxO, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && jobs_dev && M > 0 && K > 0 && njobs > 0 && maxO > 0, "linear_multi: bad args");
+  hipLaunchKernelGGL(linear_multi_kernel, dim3(cdiv(maxO, 4), njobs), dim3(256), 0, (hipStream_t)s, x, (long long)ldx, M, K,
+                     jobs_dev);
+  SDM_CHECK_LAUNCH("linear_multi");
+  return SDM_OK;
+}
+
+// backward of a small-batch linear y = x W^T + b given dy (already multiplied by act'):
+//   dx[m][k] (+)= sum_o dy[m][o] W[o][k] ;  dW[o][k] += sum_m dy[m][o] x[m][k] ; db[o] += sum_m dy[m][o]
+__global__ __launch_bounds__(256) void linear_small_bwd_dx_kernel(const float* __restrict__ dy, long long lddy,
+                                                                  const float* __restrict__ w, float* __restrict__ dx,
+                                                                  long long lddx, int M, int K, int O, int accumulate) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int m = blockIdx.y;
+  if (k >= K) return;
+  float a = 0.f;
+  for (int o = 0; o < O; ++o) a = fmaf(dy[(long long)m * lddy + o], w[(long long)o * K + k], a);
+  if (accumulate) dx[(long long)m * lddx + k] += a;
+  else dx[(long long)m * lddx + k] = a;
+}
+
+__global__ __launch_bounds__(256) void linear_small_bwd_dw_kernel(const float* __restrict__ dy, long long lddy,
+                                                                  const float* __restrict__ x, long long ldx,
+                                                                  float* __restrict__ dw, float* __restrict__ db, int M,
+                                                                  int K, int O) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int o = blockIdx.y;
+  float a = 0.f, bsum = 0.f;
+  for (int m = 0; m < M; ++m) {
+    const float d = dy[(long long)m * lddy + o];
+    bsum += d;
+    if (k < K) a = fmaf(d, x[(long long)m * ldx + k], a);
+  }
+  if (k < K) dw[(long long)o * K + k] += a;
+  if (db && k == 0) db[o] += bsum;
+}
+
+extern "C" int sdm_linear_small_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* w, float* dx,
+                                    int64_t lddx, int dx_accumulate, float* dw, float* db, int M, int K, int O,
+                                    sdm_stream_t s) {
+  SDM_CHECK_ARG(dy && w && M > 0 && K > 0 && O > 0, "linear_small_bwd: bad args");
+  hipStream_t st = (hipStream_t)s;
+  if (dx) {
+    hipLaunchKernelGGL(linear_small_bwd_dx_kernel, dim3(cdiv(K, 256), M), dim3(256), 0, st, dy, (long long)lddy, w, dx,
+                       (long long)lddx, M, K, O, dx_accumulate);
+    SDM_CHECK_LAUNCH("linear_small_bwd_dx");
+  }
+  if (dw) {
+    SDM_CHECK_ARG(x != nullptr, "linear_small_bwd: dw needs x");
+    hipLaunchKernelGGL(linear_small_bwd_dw_kernel, dim3(cdiv(K, 256), O), dim3(256), 0, st, dy, (long long)lddy, x,
+                       (long long)ldx, dw, db, M, K, O);
+    SDM_CHECK_LAUNCH("linear_small_bwd_dw");
+  }
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// generic elementwise / reductions
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ldx, long long rows, int C,
+                                                     int rows_per_block, float* __restrict__ out) {
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (long long r = r0; r < r1; ++r) a += x[r * ldx + c];
+    atomicAdd(&out[c], a);
+  }
+}
+
+extern "C" int sdm_colsum(const float* x, int64_t ldx, int rows, int C, float* out, int accumulate, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && out && rows > 0 && C > 0, "colsum: bad args");
+  hipStream_t st = (hipStream_t)s;
+  if (!accumulate) SDM_MEMSET0(out, (size_t)C * sizeof(float), st);
+  int rpb = (rows + 511) / 512;
+  if (rpb < 4) rpb = 4;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(rows, rpb)), dim3(256), 0, st, x, (long long)ldx, (long long)rows, C, rpb, out);
+  SDM_CHECK_LAUNCH("colsum");
+  return SDM_OK;
+}
+
+__global__ void silu_bwd_kernel(const float* dy, const float* z, float* dx, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    dx[i] = z ? dy[i] * sdm_dsilu(z[i]) : dy[i];
+}
+__global__ void add_kernel(const float* a, const float* b, float* y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = a[i] + b[i];
+}
+__global__ void tanh_bwd_kernel(const float* dy, const float* y, float* dx, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    dx[i] = dy[i] * (1.f - y[i] * y[i]);
+}
+static inline int ew_grid(size_t n) {
+  size_t g = (n + 255) / 256;
+  return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+__global__ void silu_kernel(const float* x, float* y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = sdm_silu(x[i]);
+}
+extern "C" int sdm_silu(const float* x, float* y, size_t n, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && y && n > 0, "silu: bad args");
+  hipLaunchKernelGGL(silu_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, y, n);
+  SDM_CHECK_LAUNCH("silu");
+  return SDM_OK;
+}
+extern "C" int sdm_silu_bwd(const float* dy, const float* z, float* dx, size_t n, sdm_stream_t s) {
+  SDM_CHECK_ARG(dy && dx && n > 0, "silu_bwd: bad args");
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, dy, z, dx, n);
+  SDM_CHECK_LAUNCH("silu_bwd");
+  return SDM_OK;
+}
+extern "C" int sdm_add(const float* a, const float* b, float* y, size_t n, sdm_stream_t s) {
+  SDM_CHECK_ARG(a && b && y && n > 0, "add: bad args");
+  hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, a, b, y, n);
+  SDM_CHECK_LAUNCH("add");
+  return SDM_OK;
+}
+extern "C" int sdm_tanh_bwd(const float* dy, const float* y, float* dx, size_t n, sdm_stream_t s) {
+  SDM_CHECK_ARG(dy && y && dx && n > 0, "tanh_bwd: bad args");
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, dy, y, dx, n);
+  SDM_CHECK_LAUNCH("tanh_bwd");
+  return SDM_OK;
+}
+
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ loss, float* __restrict__ grad, size_t n) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  const float gs = 2.0f / (float)n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float d = a[i] - b[i];
+    acc += (double)d * d;
+    if (grad) grad[i] = d * gs;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (float)((red[0] + red[1] + red[2] + red[3]) / (double)n));
+}
+extern "C" int sdm_mse(const float* a, const float* b, float* loss_out, float* grad, size_t n, sdm_stream_t s) {
+  SDM_CHECK_ARG(a && b && loss_out && n > 0, "mse: bad args");
+  hipStream_t st = (hipStream_t)s;
+  SDM_MEMSET0(loss_out, sizeof(float), st);
+  int g = ew_grid(n);
+  if (g > 512) g = 512;
+  hipLaunchKernelGGL(mse_kernel, dim3(g), dim3(256), 0, st, a, b, loss_out, grad, n);
+  SDM_CHECK_LAUNCH("mse");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// diffusion glue
+// --------------------------------------------------------------------------------------------
+__global__ void q_sample_kernel(const float* x0, const float* eps, const float* ab, float* xt, size_t per, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float a = ab[i / per];
+    xt[i] = sqrtf(a) * x0[i] + sqrtf(1.f - a) * eps[i];
+  }
+}
+extern "C" int sdm_q_sample(const float* x0, const float* eps, const float* alpha_bar, float* xt, int images,
+                            size_t per_image, sdm_stream_t s) {
+  SDM_CHECK_ARG(x0 && eps && alpha_bar && xt && images > 0 && per_image > 0, "q_sample: bad args");
+  const size_t n = (size_t)images * per_image;
+  hipLaunchKernelGGL(q_sample_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x0, eps, alpha_bar, xt, per_image, n);
+  SDM_CHECK_LAUNCH("q_sample");
+  return SDM_OK;
+}
+
+__global__ void ddpm_update_kernel(float* x, const float* eps, const float* z, const float* coef, size_t n) {
+  const float s1 = coef[0], s2 = coef[1], sg = coef[2];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float v = s1 * (x[i] - s2 * eps[i]);
+    if (z) v += sg * z[i];
+    x[i] = v;
+  }
+}
+extern "C" int sdm_ddpm_update(float* x, const float* eps, const float* z, const float* coef, size_t n, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && eps && coef && n > 0, "ddpm_update: bad args");
+  hipLaunchKernelGGL(ddpm_update_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, eps, z, coef, n);
+  SDM_CHECK_LAUNCH("ddpm_update");
+  return SDM_OK;
+}
+
+__global__ void ddim_update_kernel(float* x, const float* eps, const float* coef, float* x0_out, int last, size_t n) {
+  const float inv = coef[0], sq1m = coef[1], sa1 = coef[2], sb1 = coef[3];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float e = eps[i];
+    const float x0 = inv * (x[i] - sq1m * e);
+    if (x0_out) x0_out[i] = x0;
+    if (!last) x[i] = sa1 * x0 + sb1 * e;
+  }
+}
+extern "C" int sdm_ddim_update(float* x, const float* eps, const float* coef, float* x0_out, int last, size_t n,
+                               sdm_stream_t s) {
+  SDM_CHECK_ARG(x && eps && coef && n > 0, "ddim_update: bad args");
+  hipLaunchKernelGGL(ddim_update_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, eps, coef, x0_out, last, n);
+  SDM_CHECK_LAUNCH("ddim_update");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// fused multi-tensor Adam (no weight decay, bias-corrected; torch.optim.Adam semantics)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_multi_kernel(const sdm_adam_job* __restrict__ jobs, float lr, float b1,
+                                                         float b2, float eps, float bc1, float bc2, float gscale) {
+  const sdm_adam_job j = jobs[blockIdx.y];
+  const float step = lr / bc1;
+  const float rs = 1.0f / sqrtf(bc2);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < j.n; i += (long long)gridDim.x * 256) {
+    const float g = j.g[i] * gscale;
+    const float m = j.m[i] + (1.f - b1) * (g - j.m[i]);  // lerp, as torch does
+    const float v = b2 * j.v[i] + (1.f - b2) * g * g;
+    j.m[i] = m;
+    j.v[i] = v;
+    j.p[i] -= step * (m / (sqrtf(v) * rs + eps));
+  }
+}
+extern "C" int sdm_adam_multi(const sdm_adam_job* jobs_dev, int njobs, int64_t max_n, float lr, float beta1, float beta2,
+                              float eps, float bias_c1, float bias_c2, float grad_scale, sdm_stream_t s) {
+  SDM_CHECK_ARG(jobs_dev && njobs > 0 && max_n > 0, "adam_multi: bad args");
+  long long g = (max_n + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(adam_multi_kernel, dim3((int)g, njobs), dim3(256), 0, (hipStream_t)s, jobs_dev, lr, beta1, beta2, eps,
+                     bias_c1, bias_c2, grad_scale);
+  SDM_CHECK_LAUNCH("adam_multi");
+  return SDM_OK;
+}

@@ -1,0 +1,198 @@
+"""U-Net denoiser on MI355X — drop-in for the reference's ``models.U_Net.U_Net``.
+
+Same constructor keywords, ``forward(x, t=None, cond=None)``, ``custom_load_state_dict`` and
+``state_dict`` key names/shapes as /root/reference/models/U_Net.py:11-173, so reference
+checkpoints load with ``strict=True`` and the reference trainers/samplers can call it unchanged.
+What differs is underneath: the forward (and, in training, the backward) is a sequence of
+libsdm_hip launches over NHWC activations; see models/custom_layers.py and DESIGN.md.
+
+Gradients: under ``torch.enable_grad()`` the whole network is ONE autograd node
+(``_UNetFunction``); its backward walks the blocks in reverse with hand-written data/weight
+gradient kernels and hands autograd one gradient tensor per live parameter.  The 40 dead
+parameters of the reference (``adagn.y_shift.*``, ``attn_layers.*.norm.*``) receive ``None``
+exactly as they do there.
+"""
+import torch
+import torch.nn as nn
+
+from sdm_hip import ops
+from sdm_hip.ops import ACT_NONE, ACT_SILU, ACT_TANH, Act
+
+from .custom_layers import *  # noqa: F401,F403  (same star-export surface as the reference)
+from .custom_layers import (ConditionalEmbedding, RunCtx, UNet_ConvBlock, UNetBlock, UNetBlockType,
+                            param_grad_like)
+
+
+class U_Net(nn.Module):
+    def __init__(self, num_resnet_blocks=5, in_channel=3, out_channel=3, time_dim=64, cond_dim=None, num_layers=5,
+                 attn_layers=[2, 3, 4], num_heads=1, dim_per_head=None, groups=32, min_channel=128, max_channel=512,
+                 image_recon=False):
+        super().__init__()
+        # argument checks and their exception types follow models/U_Net.py:29-38
+        if not isinstance(num_layers, int) or not isinstance(attn_layers, list):
+            raise TypeError("Invalid type!")
+        if num_layers < 1:
+            raise ValueError("Invalid num layer value!")
+        for a in attn_layers:
+            if not isinstance(a, int):
+                raise ValueError("Invalid type in attention layer!")
+            if a < 0 or a >= num_layers:
+                raise ValueError("Invalid Attention Layer values!")
+
+        # the reference doubles an un-clipped running value (models/U_Net.py:41-46)
+        ch, c = [min_channel], min_channel
+        for _ in range(num_layers):
+            c *= 2
+            ch.append(max_channel if c > max_channel else c)
+        self.channel_layers = ch
+        self.num_layers, self.image_recon = num_layers, image_recon
+        self.in_channel, self.out_channel = in_channel, out_channel
+
+        self.cond_emb = ConditionalEmbedding(time_dim, cond_dim) if time_dim is not None else None
+        self.in_layer = nn.Sequential(UNet_ConvBlock(in_channel, ch[0]), UNet_ConvBlock(ch[0], ch[0]))
+        self.down_layers = nn.ModuleList(
+            UNetBlock(ch[k], ch[k + 1], time_dim, num_resnet_blocks, k in attn_layers, num_heads, dim_per_head, groups,
+                      UNetBlockType.DOWN) for k in range(num_layers))
+        self.middle_layer = nn.Sequential(UNet_ConvBlock(ch[-1], ch[-1]), UNet_ConvBlock(ch[-1], ch[-1]))
+        self.up_layers = nn.ModuleList(
+            UNetBlock(ch[k + 1] * 2, ch[k], time_dim, num_resnet_blocks, k in attn_layers, num_heads, dim_per_head,
+                      groups, UNetBlockType.UP) for k in range(num_layers - 1, -1, -1))
+        outs = [UNet_ConvBlock(ch[0], ch[0]), UNet_ConvBlock(ch[0], out_channel, use_activation=False)]
+        if image_recon:
+            outs.append(nn.Tanh())
+        self.out_layers = nn.Sequential(*outs)
+
+    # ------------------------------------------------------------------ checkpoints
+    def custom_load_state_dict(self, state_dict):
+        """Lenient loader (models/U_Net.py:132-145): unknown names and shape mismatches are skipped."""
+        own = self.state_dict()
+        for name, param in state_dict.items():
+            if name not in own:
+                print(f"No Layer found: {name}, skipping")
+                continue
+            if own[name].shape != param.data.shape:
+                print(f"Skipped: {name}")
+                continue
+            if isinstance(param, nn.Parameter):
+                param = param.data
+            own[name].copy_(param)
+
+    def live_parameters(self):
+        """(name, parameter) pairs that receive gradients, in registration order."""
+        return [(n, p) for n, p in self.named_parameters()
+                if ".adagn.y_shift." not in n and not (".attn_layers." in n and ".norm." in n)]
+
+    # ------------------------------------------------------------------ forward
+    def _check_input(self, x):
+        if x.dim() != 4 or x.shape[1] != self.in_channel:
+            raise RuntimeError(f"expected input [N, {self.in_channel}, H, W], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("U_Net runs on MI355X only: move the module and inputs to 'cuda' "
+                               "(there is no CPU fallback; the CPU oracle lives under oracle/)")
+        div = 1 << self.num_layers
+        if x.shape[2] % div or x.shape[3] % div:
+            raise RuntimeError(f"H and W must be multiples of 2**num_layers = {div} (skip connections must align)")
+
+    def _run(self, ctx, x, t, cond):
+        x = x.to(torch.float32).contiguous()
+        emb = None
+        if self.cond_emb is not None:
+            emb = self.cond_emb.run(ctx, t.to(x.device), None if cond is None else cond.to(x.device))
+            if ctx.train and emb.shape[0] != x.shape[0]:
+                raise RuntimeError("training needs one timestep per image (t of shape [N])")
+            ctx.emb = emb
+        stem = self.in_layer[0].conv_layer.conv
+        a = ops.stem_conv(x, stem.taps(), stem.bias, ACT_SILU, save_z=ctx.train)
+        if ctx.train:
+            ctx.rec["x"] = x
+        a, _ = self.in_layer[1].run(ctx, a)
+        skips = []
+        for blk in self.down_layers:
+            a = blk.run(ctx, a, emb)
+            skips.append(a)
+        a, _ = self.middle_layer[0].run(ctx, a)
+        a, _ = self.middle_layer[1].run(ctx, a)
+        for blk in self.up_layers:
+            s = skips.pop()
+            a = blk.run(ctx, Act(a.t, a.n, a.h, a.w, t2=s.t, z=a.z), emb)     # torch.cat((x, skip), 1) never materialised
+        a, _ = self.out_layers[0].run(ctx, a)
+        head = self.out_layers[1].conv_layer.conv
+        if ctx.train:
+            ctx.rec["head_in"] = a
+        return ops.head_conv(a, head.taps(), head.bias, ACT_TANH if self.image_recon else ACT_NONE)
+
+    def forward(self, x, t=None, cond=None):
+        self._check_input(x)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            live = self.live_parameters()
+            return _UNetFunction.apply(self, x, t, cond, *[p for _, p in live])
+        return self._run(RunCtx(False), x, t, cond)
+
+    # ------------------------------------------------------------------ backward
+    def _backward(self, ctx, out, dout, grads):
+        """grads: {parameter: gradient buffer with the parameter's layout}, filled in place."""
+        L = self.num_layers
+        dout = dout.to(torch.float32).contiguous()
+        if self.image_recon:
+            dout = ops.tanh_bwd(dout, out)
+        if ctx.emb is not None:
+            ctx.demb = torch.zeros_like(ctx.emb)
+        head = self.out_layers[1].conv_layer.conv
+        hin = ctx.rec["head_in"]
+        n, H, W = hin.n, hin.h, hin.w
+        st = ops._stream()
+        ops.lib.call("sdm_head_conv_wgrad", hin.t.data_ptr(), dout.data_ptr(), head.grad_taps(grads[head.weight]).data_ptr(),
+                     grads[head.bias].data_ptr(), n, hin.c, H, W, self.out_channel, st)
+        dz = torch.empty_like(hin.t)
+        ops.lib.call("sdm_head_conv_dgrad", dout.data_ptr(), head.taps().data_ptr(), dz.data_ptr(), hin.z.data_ptr(), n,
+                     hin.c, H, W, self.out_channel, st)
+        dz = self.out_layers[0].backward(ctx, dz, grads)                 # -> dz of the last up-sampler
+        pending = {}
+        for idx in range(L - 1, -1, -1):                                   # up_layers[idx] handles level k = L-1-idx
+            blk = self.up_layers[idx]
+            g = blk.backward(ctx, dz, grads)                               # [rows, c_prev + c_skip]
+            c_prev = ctx.rec[blk.res_layers[0].conv_block_1][0].c1
+            dz = g[:, :c_prev]                                             # silu' of the producer already applied
+            pending[L - 1 - idx] = g[:, c_prev:]                           # skip half: finished on the way down
+        dz = self.middle_layer[1].backward(ctx, dz, grads)
+        dz = self.middle_layer[0].backward(ctx, dz, grads, res=pending[L - 1])
+        for k in range(L - 1, -1, -1):
+            dz = self.down_layers[k].backward(ctx, dz, grads, extra=pending[k - 1] if k >= 1 else None)
+        dz = self.in_layer[1].backward(ctx, dz, grads)
+        stem = self.in_layer[0].conv_layer.conv
+        x = ctx.rec["x"]
+        ops.lib.call("sdm_stem_conv_wgrad", x.data_ptr(), dz.data_ptr(), stem.grad_taps(grads[stem.weight]).data_ptr(),
+                     grads[stem.bias].data_ptr(), x.shape[0], x.shape[1], x.shape[2], x.shape[3], stem.cout, st)
+        if self.cond_emb is not None:
+            self.cond_emb.backward(ctx, ctx.demb, grads)
+
+    def loss_and_grads(self, x, t, cond, target, grads=None):
+        """One training forward+backward of mean-squared error against ``target`` without going through autograd:
+        returns (loss tensor [1], {param: grad}).  Used by the fused trainer and the benchmark."""
+        self._check_input(x)
+        ctx = RunCtx(True)
+        out = self._run(ctx, x, t, cond)
+        loss, dout = ops.mse(out, target.contiguous(), want_grad=True)
+        if grads is None:
+            grads = {p: param_grad_like(p) for _, p in self.live_parameters()}
+        self._backward(ctx, out, dout, grads)
+        return loss, grads
+
+
+class _UNetFunction(torch.autograd.Function):
+    """The whole U-Net as one autograd node (inputs: the live parameters)."""
+
+    @staticmethod
+    def forward(fctx, net, x, t, cond, *params):
+        ctx = RunCtx(True)
+        out = net._run(ctx, x.detach(), t, cond)
+        fctx.net, fctx.run, fctx.out, fctx.params = net, ctx, out, params
+        return out
+
+    @staticmethod
+    def backward(fctx, dout):
+        net = fctx.net
+        grads = {p: param_grad_like(p) for p in fctx.params}
+        net._backward(fctx.run, fctx.out, dout, grads)
+        fctx.run = None
+        return (None, None, None, None) + tuple(grads[p] for p in fctx.params)

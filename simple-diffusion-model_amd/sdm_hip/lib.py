@@ -1,0 +1,140 @@
+"""ctypes binding of libsdm_hip.so (C ABI declared in include/sdm_hip.h).
+
+There is deliberately no fallback: if the library is missing the import fails, and every
+launch wrapper raises on a non-zero return code.  Nothing here computes anything.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdm_hip.so")
+
+MAX_PHASE, MAX_TAPS = 4, 16
+ACT_NONE, ACT_SILU, ACT_TANH = 0, 1, 2
+
+fp = C.c_void_p  # device pointers travel as integers
+
+
+class Rows(C.Structure):
+    _fields_ = [("p0", fp), ("p1", fp), ("csplit", C.c_int), ("ld0", C.c_int64), ("ld1", C.c_int64),
+                ("scale", fp), ("shift", fp), ("aff_nstride", C.c_int), ("H", C.c_int), ("W", C.c_int)]
+
+
+class IgemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("batch", C.c_int), ("bdiv", C.c_int),
+        ("a", Rows), ("a_bs0", C.c_int64), ("a_bs1", C.c_int64),
+        ("Ht", C.c_int), ("Wt", C.c_int), ("sstride", C.c_int), ("nphase", C.c_int),
+        ("ntaps", C.c_int * MAX_PHASE),
+        ("tap_dy", (C.c_int8 * MAX_TAPS) * MAX_PHASE),
+        ("tap_dx", (C.c_int8 * MAX_TAPS) * MAX_PHASE),
+        ("tap_w", (C.c_uint8 * MAX_TAPS) * MAX_PHASE),
+        ("b", fp), ("ldb", C.c_int64), ("b_tap_stride", C.c_int64), ("b_kmajor", C.c_int),
+        ("b_bs0", C.c_int64), ("b_bs1", C.c_int64),
+        ("ostride", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
+        ("ph_oy", C.c_int * MAX_PHASE), ("ph_ox", C.c_int * MAX_PHASE),
+        ("out", fp), ("ldo", C.c_int64), ("o_bs0", C.c_int64), ("o_bs1", C.c_int64),
+        ("alpha", C.c_float), ("bias", fp), ("act", C.c_int), ("out_preact", fp),
+        ("res", fp), ("ldres", C.c_int64), ("r_bs0", C.c_int64), ("r_bs1", C.c_int64),
+        ("res2", fp), ("ldres2", C.c_int64),
+        ("dact_z", fp), ("ldz", C.c_int64), ("dact_ncols", C.c_int),
+        ("ws", fp), ("ws_bytes", C.c_size_t),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("N", C.c_int), ("images", C.c_int), ("Hk", C.c_int), ("Wk", C.c_int),
+        ("batch", C.c_int), ("bdiv", C.c_int),
+        ("g", Rows), ("g_stride", C.c_int), ("x", Rows), ("x_stride", C.c_int),
+        ("g_bs0", C.c_int64), ("g_bs1", C.c_int64), ("x_bs0", C.c_int64), ("x_bs1", C.c_int64),
+        ("ntaps", C.c_int),
+        ("g_dy", C.c_int8 * MAX_TAPS), ("g_dx", C.c_int8 * MAX_TAPS),
+        ("x_dy", C.c_int8 * MAX_TAPS), ("x_dx", C.c_int8 * MAX_TAPS),
+        ("tap_w", C.c_uint8 * MAX_TAPS),
+        ("dw", fp), ("ldw", C.c_int64), ("w_tap_stride", C.c_int64), ("w_bs0", C.c_int64), ("w_bs1", C.c_int64),
+        ("alpha", C.c_float), ("accumulate", C.c_int),
+    ]
+
+
+class LinearJob(C.Structure):
+    _fields_ = [("w", fp), ("b", fp), ("out", fp), ("O", C.c_int), ("pad", C.c_int)]
+
+
+class AdamJob(C.Structure):
+    _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("n", C.c_int64)]
+
+
+class SdmError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+        "There is no CPU or PyTorch fallback for the U-Net kernels.")
+
+_lib = C.CDLL(LIB_PATH)
+
+_i, _i64, _f, _sz = C.c_int, C.c_int64, C.c_float, C.c_size_t
+_PROTOS = {
+    "sdm_version": (C.c_int, []),
+    "sdm_last_error": (C.c_char_p, []),
+    "sdm_device_info": (C.c_int, [C.POINTER(C.c_int)]),
+    "sdm_struct_size": (_sz, [_i]),
+    "sdm_igemm": (_i, [C.POINTER(IgemmDesc), fp]),
+    "sdm_igemm_workspace_bytes": (_sz, [C.POINTER(IgemmDesc)]),
+    "sdm_wgrad": (_i, [C.POINTER(WgradDesc), fp]),
+    "sdm_stem_conv": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
+    "sdm_head_conv": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
+    "sdm_head_conv_dgrad": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "sdm_stem_conv_wgrad": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "sdm_head_conv_wgrad": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "sdm_gn_affine": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, fp, fp, fp, fp]),
+    "sdm_affine_residual": (_i, [fp, _i64, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, _i, _i, _i, fp]),
+    "sdm_gn_adagn_bwd": (_i, [fp, _i64, fp, _i64, fp, _i64, _i, _i, _i, _i, fp, fp, fp, _i, fp, fp, fp, _i64,
+                              fp, fp, fp, fp, fp]),
+    "sdm_col_softmax": (_i, [fp, _i, _i, _i64, fp]),
+    "sdm_col_softmax_bwd": (_i, [fp, fp, _i, _i, _i64, _f, fp]),
+    "sdm_sinusoid": (_i, [fp, fp, _i, _i, fp, fp]),
+    "sdm_linear_small": (_i, [fp, _i64, fp, fp, fp, fp, _i64, fp, _i, _i, _i, _i, fp]),
+    "sdm_linear_multi": (_i, [fp, _i64, _i, _i, fp, _i, _i, fp]),
+    "sdm_linear_small_bwd": (_i, [fp, _i64, fp, _i64, fp, fp, _i64, _i, fp, fp, _i, _i, _i, fp]),
+    "sdm_colsum": (_i, [fp, _i64, _i, _i, fp, _i, fp]),
+    "sdm_silu": (_i, [fp, fp, _sz, fp]),
+    "sdm_silu_bwd": (_i, [fp, fp, fp, _sz, fp]),
+    "sdm_add": (_i, [fp, fp, fp, _sz, fp]),
+    "sdm_mse": (_i, [fp, fp, fp, fp, _sz, fp]),
+    "sdm_tanh_bwd": (_i, [fp, fp, fp, _sz, fp]),
+    "sdm_q_sample": (_i, [fp, fp, fp, fp, _i, _sz, fp]),
+    "sdm_ddpm_update": (_i, [fp, fp, fp, fp, _sz, fp]),
+    "sdm_ddim_update": (_i, [fp, fp, fp, fp, _i, _sz, fp]),
+    "sdm_adam_multi": (_i, [fp, _i, _i64, _f, _f, _f, _f, _f, _f, _f, fp]),
+}
+EXPORTS = tuple(_PROTOS)
+
+for _name, (_res, _args) in _PROTOS.items():
+    _fn = getattr(_lib, _name)       # AttributeError here == symbol missing from the .so
+    _fn.restype, _fn.argtypes = _res, _args
+
+for _which, _cls in enumerate((IgemmDesc, WgradDesc, Rows, LinearJob, AdamJob)):
+    if _lib.sdm_struct_size(_which) != C.sizeof(_cls):
+        raise ImportError(f"ABI mismatch for {_cls.__name__}: C {_lib.sdm_struct_size(_which)} vs ctypes {C.sizeof(_cls)}")
+
+
+def last_error():
+    return _lib.sdm_last_error().decode()
+
+
+def call(name, *args):
+    rc = getattr(_lib, name)(*args)
+    if rc != 0:
+        raise SdmError(f"{name} failed (rc={rc}): {last_error()}")
+
+
+def raw(name):
+    return getattr(_lib, name)
+
+
+def version():
+    return _lib.sdm_version()

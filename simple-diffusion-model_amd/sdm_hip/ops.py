@@ -1,0 +1,520 @@
+"""Host-side launch helpers: torch tensors in, C-ABI calls out.  No arithmetic happens in
+Python; torch is used for device memory and streams only.
+
+Activations are NHWC "pixel rows x channels" (class Act); conv weights are tap-major
+``[taps, c_out, c_in]`` views of the parameters (see models/custom_layers.py).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib
+from .lib import ACT_NONE, ACT_SILU, ACT_TANH, IgemmDesc, Rows, WgradDesc
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class Act:
+    """An activation as pixel rows: ``t`` is [n*h*w, c] (row pitch t.stride(0)); ``t2`` an optional second
+    tensor concatenated on channels; ``scale``/``shift`` an optional pending per-(image,channel) affine
+    (deferred GroupNorm+AdaGN).  ``z`` is the pre-activation kept for backward when training."""
+    __slots__ = ("t", "n", "h", "w", "t2", "scale", "shift", "z")
+
+    def __init__(self, t, n, h, w, t2=None, scale=None, shift=None, z=None):
+        self.t, self.n, self.h, self.w, self.t2 = t, n, h, w, t2
+        self.scale, self.shift, self.z = scale, shift, z
+
+    @property
+    def c1(self):
+        return self.t.shape[1]
+
+    @property
+    def c(self):
+        return self.t.shape[1] + (self.t2.shape[1] if self.t2 is not None else 0)
+
+    @property
+    def rows(self):
+        return self.n * self.h * self.w
+
+    def with_affine(self, scale, shift):
+        return Act(self.t, self.n, self.h, self.w, self.t2, scale, shift, self.z)
+
+
+def fill_rows(r, a, h=None, w=None):
+    r.p0 = _p(a.t)
+    r.p1 = _p(a.t2)
+    r.csplit = a.c1
+    r.ld0 = a.t.stride(0)
+    r.ld1 = a.t2.stride(0) if a.t2 is not None else 0
+    r.scale = _p(a.scale)
+    r.shift = _p(a.shift)
+    r.aff_nstride = 0 if (a.scale is None or a.scale.shape[0] == 1) else a.scale.stride(0)
+    r.H = a.h if h is None else h
+    r.W = a.w if w is None else w
+
+
+def plain_rows(r, t, rows=None):
+    r.p0 = _p(t)
+    r.p1 = None
+    r.csplit = 1 << 30
+    r.ld0 = t.stride(0)
+    r.ld1 = 0
+    r.scale = r.shift = None
+    r.aff_nstride = 0
+    r.H = t.shape[0] if rows is None else rows
+    r.W = 1
+
+
+class _Workspace:
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if nbytes == 0:
+            return None
+        if self.buf is None or self.buf.numel() * 4 < nbytes or self.buf.device != device:
+            if torch.cuda.is_current_stream_capturing():
+                raise lib.SdmError("split-K workspace must be sized by a warm-up call before graph capture")
+            self.buf = torch.empty((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)
+        return self.buf
+
+
+WS = _Workspace()
+
+# ---- tap tables -----------------------------------------------------------------------------
+_C3 = [(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+# ConvTranspose2d(k4,s2,p1): output row 2y+a takes kernel rows {1,3} (a=0) or {0,2} (a=1)
+_CT_1D = {0: [(1, 0), (3, -1)], 1: [(0, 1), (2, 0)]}      # (k, d)
+# data-gradient of Conv2d(k3,s2,p1): input row 2y+a receives from kernel rows {1} (a=0) or {0,2} (a=1)
+_S2D_1D = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}
+
+
+def _set_taps(d, phase, taps):
+    d.ntaps[phase] = len(taps)
+    for i, (dy, dx, w) in enumerate(taps):
+        d.tap_dy[phase][i], d.tap_dx[phase][i], d.tap_w[phase][i] = dy, dx, w
+
+
+def _launch_igemm(d, device):
+    need = lib.raw("sdm_igemm_workspace_bytes")(C.byref(d))
+    ws = WS.get(need, device)
+    d.ws = _p(ws)
+    d.ws_bytes = ws.numel() * 4 if ws is not None else 0
+    lib.call("sdm_igemm", C.byref(d), _stream())
+
+
+def _base_desc(M, N, K):
+    d = IgemmDesc()
+    d.M, d.N, d.K, d.batch, d.bdiv = M, N, K, 1, 1
+    d.sstride = d.ostride = d.nphase = 1
+    d.alpha = 1.0
+    return d
+
+
+def conv_out_hw(h, w, kind):
+    if kind == "c3s1":
+        return h, w
+    if kind == "c3s2":
+        return (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if kind == "ct4":
+        return 2 * h, 2 * w
+    raise ValueError(kind)
+
+
+def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False):
+    """x: Act; wt: [taps, c_out, c_in] contiguous view; returns Act (plain)."""
+    T, cout, cin = wt.shape
+    assert cin == x.c, (cin, x.c)
+    ho, wo = conv_out_hw(x.h, x.w, kind)
+    out = torch.empty((x.n * ho * wo, cout), dtype=torch.float32, device=wt.device)
+    z = torch.empty_like(out) if save_z else None
+    if kind == "ct4":
+        d = _base_desc(x.rows, cout, cin)
+        d.Ht, d.Wt = x.h, x.w
+        d.nphase, d.ostride = 4, 2
+        for a in (0, 1):
+            for b in (0, 1):
+                ph = a * 2 + b
+                _set_taps(d, ph, [(dy, dx, ky * 4 + kx) for (ky, dy) in _CT_1D[a] for (kx, dx) in _CT_1D[b]])
+                d.ph_oy[ph], d.ph_ox[ph] = a, b
+    else:
+        s = 1 if kind == "c3s1" else 2
+        d = _base_desc(x.n * ho * wo, cout, cin)
+        d.Ht, d.Wt, d.sstride = ho, wo, s
+        _set_taps(d, 0, _C3)
+    fill_rows(d.a, x)
+    d.b, d.ldb, d.b_tap_stride, d.b_kmajor = _p(wt), cin, cout * cin, 0
+    d.Ho, d.Wo = ho, wo
+    d.out, d.ldo = _p(out), out.stride(0)
+    d.bias, d.act, d.out_preact = _p(bias), act, _p(z)
+    _launch_igemm(d, wt.device)
+    return Act(out, x.n, ho, wo, z=z)
+
+
+def conv_dgrad(g, g_hw, wt, kind, x_hw, n, res=None, res2=None, dact_z=None, dact_ncols=0, out=None):
+    """Data gradient of conv_fwd.  g: [n*ho*wo, c_out] (pitch g.stride(0)); returns dx [n*h*w, c_in]."""
+    T, cout, cin = wt.shape
+    ho, wo = g_hw
+    h, w = x_hw
+    if out is None:
+        out = torch.empty((n * h * w, cin), dtype=torch.float32, device=wt.device)
+    ga = Act(g, n, ho, wo)
+    if kind == "c3s1":
+        d = _base_desc(n * h * w, cin, cout)
+        d.Ht, d.Wt = h, w
+        _set_taps(d, 0, [(-dy, -dx, wi) for (dy, dx, wi) in _C3])
+    elif kind == "c3s2":
+        ht, wt_ = (h + 1) // 2, (w + 1) // 2
+        d = _base_desc(n * ht * wt_, cin, cout)
+        d.Ht, d.Wt, d.nphase, d.ostride = ht, wt_, 4, 2
+        for a in (0, 1):
+            for b in (0, 1):
+                ph = a * 2 + b
+                _set_taps(d, ph, [(dy, dx, ky * 3 + kx) for (ky, dy) in _S2D_1D[a] for (kx, dx) in _S2D_1D[b]])
+                d.ph_oy[ph], d.ph_ox[ph] = a, b
+    elif kind == "ct4":
+        d = _base_desc(n * h * w, cin, cout)
+        d.Ht, d.Wt, d.sstride = h, w, 2
+        _set_taps(d, 0, [(ky - 1, kx - 1, ky * 4 + kx) for ky in range(4) for kx in range(4)])
+    else:
+        raise ValueError(kind)
+    fill_rows(d.a, ga)
+    d.b, d.ldb, d.b_tap_stride, d.b_kmajor = _p(wt), cin, cout * cin, 1
+    d.Ho, d.Wo = h, w
+    d.out, d.ldo = _p(out), out.stride(0)
+    d.act = ACT_NONE
+    if res is not None:
+        d.res, d.ldres = _p(res), res.stride(0)
+    if res2 is not None:
+        d.res2, d.ldres2 = _p(res2), res2.stride(0)
+    if dact_z is not None:
+        d.dact_z, d.ldz, d.dact_ncols = _p(dact_z), dact_z.stride(0), dact_ncols
+    _launch_igemm(d, wt.device)
+    return out
+
+
+def conv_wgrad(g, g_hw, x, kind, dwt, accumulate=False):
+    """dwt[tap][co][ci] (+)= sum_p g[.][co] * x~[.][ci]; g: [n*ho*wo, c_out] rows; x: Act (input of the conv)."""
+    T, cout, cin = dwt.shape
+    ho, wo = g_hw
+    d = WgradDesc()
+    d.M, d.N, d.batch, d.bdiv = cout, cin, 1, 1
+    d.images = x.n
+    plain_rows(d.g, g)
+    d.g.H, d.g.W = ho, wo
+    fill_rows(d.x, x)
+    if kind == "ct4":
+        d.Hk, d.Wk = x.h, x.w
+        d.g_stride, d.x_stride = 2, 1
+        taps = [(ky - 1, kx - 1, 0, 0, ky * 4 + kx) for ky in range(4) for kx in range(4)]
+    else:
+        s = 1 if kind == "c3s1" else 2
+        d.Hk, d.Wk = ho, wo
+        d.g_stride, d.x_stride = 1, s
+        taps = [(0, 0, ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+    d.ntaps = len(taps)
+    for i, (gdy, gdx, xdy, xdx, wi) in enumerate(taps):
+        d.g_dy[i], d.g_dx[i], d.x_dy[i], d.x_dx[i], d.tap_w[i] = gdy, gdx, xdy, xdx, wi
+    d.dw, d.ldw, d.w_tap_stride = _p(dwt), cin, cout * cin
+    d.alpha, d.accumulate = 1.0, int(accumulate)
+    lib.call("sdm_wgrad", C.byref(d), _stream())
+
+
+def linear_rows(x, W, b, act=ACT_NONE, res=None, save_z=False, out=None):
+    """Token linear on the matrix cores: x [rows, K] (any pitch) @ W[O, K]^T + b (+ res)."""
+    rows, K = x.shape
+    O = W.shape[0]
+    if out is None:
+        out = torch.empty((rows, O), dtype=torch.float32, device=x.device)
+    d = _base_desc(rows, O, K)
+    d.Ht, d.Wt = rows, 1
+    plain_rows(d.a, x)
+    d.b, d.ldb, d.b_tap_stride, d.b_kmajor = _p(W), W.stride(0), 0, 0
+    d.ntaps[0] = 1
+    d.Ho, d.Wo = rows, 1
+    d.out, d.ldo = _p(out), out.stride(0)
+    d.bias, d.act = _p(b), act
+    if res is not None:
+        d.res, d.ldres = _p(res), res.stride(0)
+    _launch_igemm(d, x.device)
+    return out
+
+
+def linear_rows_dgrad(g, W, res=None, out=None):
+    """dx [rows, K] = g [rows, O] @ W[O, K] (+ res)."""
+    rows, O = g.shape
+    K = W.shape[1]
+    if out is None:
+        out = torch.empty((rows, K), dtype=torch.float32, device=g.device)
+    d = _base_desc(rows, K, O)
+    d.Ht, d.Wt = rows, 1
+    plain_rows(d.a, g)
+    d.b, d.ldb, d.b_tap_stride, d.b_kmajor = _p(W), W.stride(0), 0, 1
+    d.ntaps[0] = 1
+    d.Ho, d.Wo = rows, 1
+    d.out, d.ldo = _p(out), out.stride(0)
+    if res is not None:
+        d.res, d.ldres = _p(res), res.stride(0)
+    _launch_igemm(d, g.device)
+    return out
+
+
+def linear_rows_wgrad(g, x, dW, accumulate=False):
+    """dW[O, K] (+)= g[rows, O]^T @ x[rows, K]."""
+    rows, O = g.shape
+    K = x.shape[1]
+    d = WgradDesc()
+    d.M, d.N, d.batch, d.bdiv = O, K, 1, 1
+    d.images, d.Hk, d.Wk = 1, rows, 1
+    plain_rows(d.g, g)
+    plain_rows(d.x, x)
+    d.g_stride = d.x_stride = 1
+    d.ntaps = 1
+    d.dw, d.ldw, d.w_tap_stride = _p(dW), dW.stride(0), 0
+    d.alpha, d.accumulate = 1.0, int(accumulate)
+    lib.call("sdm_wgrad", C.byref(d), _stream())
+
+
+def _pad4(s):
+    return (s + 3) // 4 * 4
+
+
+def attention_core_fwd(qkv, n, S, heads, dk):
+    """qkv: [n*S, heads*3*dk] with per-head [q|k|v] chunks (custom_layers.py:138-141).
+    Returns (res [n*S, heads*dk], P [n*heads, S, Sp]) with P the column-softmaxed scores."""
+    dev = qkv.device
+    Sp = _pad4(S)
+    ld = qkv.stride(0)
+    P = torch.empty((n * heads, S, Sp), dtype=torch.float32, device=dev)
+    d = _base_desc(S, S, dk)
+    d.batch, d.bdiv = n * heads, heads
+    d.Ht, d.Wt = S, 1
+    plain_rows(d.a, qkv, rows=S)
+    d.a_bs0, d.a_bs1 = S * ld, 3 * dk
+    d.b, d.ldb, d.b_kmajor = qkv.data_ptr() + 4 * dk, ld, 0
+    d.b_bs0, d.b_bs1 = S * ld, 3 * dk
+    d.ntaps[0] = 1
+    d.Ho, d.Wo = S, 1
+    d.out, d.ldo, d.o_bs0, d.o_bs1 = _p(P), Sp, heads * S * Sp, S * Sp
+    d.alpha = float(dk) ** -0.5
+    _launch_igemm(d, dev)
+    lib.call("sdm_col_softmax", _p(P), n * heads, S, Sp, _stream())
+    res = torch.empty((n * S, heads * dk), dtype=torch.float32, device=dev)
+    d = _base_desc(S, dk, S)
+    d.batch, d.bdiv = n * heads, heads
+    d.Ht, d.Wt = S, 1
+    plain_rows(d.a, P[0], rows=S)
+    d.a.ld0 = Sp
+    d.a_bs0, d.a_bs1 = heads * S * Sp, S * Sp
+    d.b, d.ldb, d.b_kmajor = qkv.data_ptr() + 8 * dk, ld, 1
+    d.b_bs0, d.b_bs1 = S * ld, 3 * dk
+    d.ntaps[0] = 1
+    d.Ho, d.Wo = S, 1
+    d.out, d.ldo, d.o_bs0, d.o_bs1 = _p(res), heads * dk, S * heads * dk, dk
+    _launch_igemm(d, dev)
+    return res, P
+
+
+def attention_core_bwd(dres, qkv, P, n, S, heads, dk):
+    """Returns dqkv [n*S, heads*3*dk] given dres [n*S, heads*dk]."""
+    dev = qkv.device
+    Sp = P.shape[2]
+    ld = qkv.stride(0)
+    hd = heads * dk
+    dqkv = torch.empty_like(qkv)
+    ldq = dqkv.stride(0)
+    st = _stream()
+    # dV[j][dd] = sum_i P[i][j] dres[i][dd]
+    w = WgradDesc()
+    w.M, w.N, w.batch, w.bdiv = S, dk, n * heads, heads
+    w.images, w.Hk, w.Wk = 1, S, 1
+    plain_rows(w.g, P[0], rows=S)
+    w.g.ld0 = Sp
+    w.g_bs0, w.g_bs1 = heads * S * Sp, S * Sp
+    plain_rows(w.x, dres, rows=S)
+    w.x_bs0, w.x_bs1 = S * dres.stride(0), dk
+    w.g_stride = w.x_stride = 1
+    w.ntaps = 1
+    w.dw, w.ldw = dqkv.data_ptr() + 8 * dk, ldq
+    w.w_bs0, w.w_bs1 = S * ldq, 3 * dk
+    w.alpha, w.accumulate = 1.0, 0
+    lib.call("sdm_wgrad", C.byref(w), st)
+    # dP[i][j] = sum_dd dres[i][dd] v[j][dd]
+    dP = torch.empty_like(P)
+    d = _base_desc(S, S, dk)
+    d.batch, d.bdiv = n * heads, heads
+    d.Ht, d.Wt = S, 1
+    plain_rows(d.a, dres, rows=S)
+    d.a_bs0, d.a_bs1 = S * dres.stride(0), dk
+    d.b, d.ldb, d.b_kmajor = qkv.data_ptr() + 8 * dk, ld, 0
+    d.b_bs0, d.b_bs1 = S * ld, 3 * dk
+    d.ntaps[0] = 1
+    d.Ho, d.Wo = S, 1
+    d.out, d.ldo, d.o_bs0, d.o_bs1 = _p(dP), Sp, heads * S * Sp, S * Sp
+    _launch_igemm(d, dev)
+    lib.call("sdm_col_softmax_bwd", _p(P), _p(dP), n * heads, S, Sp, float(dk) ** -0.5, st)
+    # dQ[i][dd] = sum_j dS[i][j] k[j][dd]
+    d = _base_desc(S, dk, S)
+    d.batch, d.bdiv = n * heads, heads
+    d.Ht, d.Wt = S, 1
+    plain_rows(d.a, dP[0], rows=S)
+    d.a.ld0 = Sp
+    d.a_bs0, d.a_bs1 = heads * S * Sp, S * Sp
+    d.b, d.ldb, d.b_kmajor = qkv.data_ptr() + 4 * dk, ld, 1
+    d.b_bs0, d.b_bs1 = S * ld, 3 * dk
+    d.ntaps[0] = 1
+    d.Ho, d.Wo = S, 1
+    d.out, d.ldo, d.o_bs0, d.o_bs1 = _p(dqkv), ldq, S * ldq, 3 * dk
+    _launch_igemm(d, dev)
+    # dK[j][dd] = sum_i dS[i][j] q[i][dd]
+    w = WgradDesc()
+    w.M, w.N, w.batch, w.bdiv = S, dk, n * heads, heads
+    w.images, w.Hk, w.Wk = 1, S, 1
+    plain_rows(w.g, dP[0], rows=S)
+    w.g.ld0 = Sp
+    w.g_bs0, w.g_bs1 = heads * S * Sp, S * Sp
+    plain_rows(w.x, qkv, rows=S)
+    w.x_bs0, w.x_bs1 = S * ld, 3 * dk
+    w.g_stride = w.x_stride = 1
+    w.ntaps = 1
+    w.dw, w.ldw = dqkv.data_ptr() + 4 * dk, ldq
+    w.w_bs0, w.w_bs1 = S * ldq, 3 * dk
+    w.alpha, w.accumulate = 1.0, 0
+    lib.call("sdm_wgrad", C.byref(w), st)
+    return dqkv
+
+
+# ---- pointwise / reductions -------------------------------------------------------------------
+def stem_conv(x_nchw, wt, bias, act=ACT_SILU, save_z=False):
+    n, cin, h, w = x_nchw.shape
+    cout = wt.shape[1]
+    out = torch.empty((n * h * w, cout), dtype=torch.float32, device=wt.device)
+    z = torch.empty_like(out) if save_z else None
+    lib.call("sdm_stem_conv", _p(x_nchw), _p(wt), _p(bias), _p(out), _p(z), n, cin, h, w, cout, act, _stream())
+    return Act(out, n, h, w, z=z)
+
+
+def head_conv(x, wt, bias, act=ACT_NONE):
+    cout = wt.shape[1]
+    out = torch.empty((x.n, cout, x.h, x.w), dtype=torch.float32, device=wt.device)
+    lib.call("sdm_head_conv", _p(x.t), _p(wt), _p(bias), _p(out), x.n, x.c, x.h, x.w, cout, act, _stream())
+    return out
+
+
+def gn_affine(y, gamma, beta, mod, groups=32, eps=1e-5):
+    """y: Act (plain).  Returns (scale, shift, mean, rstd); scale/shift are [n, C]."""
+    C_ = y.c
+    dev = y.t.device
+    scale = torch.empty((y.n, C_), dtype=torch.float32, device=dev)
+    shift = torch.empty_like(scale)
+    mean = torch.empty((y.n, groups), dtype=torch.float32, device=dev)
+    rstd = torch.empty_like(mean)
+    mns = 0 if (mod is None or mod.shape[0] == 1) else mod.stride(0)
+    lib.call("sdm_gn_affine", _p(y.t), y.t.stride(0), y.n, y.h * y.w, C_, groups, eps, _p(gamma), _p(beta), _p(mod), mns,
+             _p(scale), _p(shift), _p(mean), _p(rstd), _stream())
+    return scale, shift, mean, rstd
+
+
+def affine_residual(y, scale, shift, x):
+    """out = scale*y + shift + cat(x.t, x.t2)  (plain Act)."""
+    out = torch.empty((y.rows, y.c), dtype=torch.float32, device=y.t.device)
+    ans = 0 if (scale is None or scale.shape[0] == 1) else scale.stride(0)
+    lib.call("sdm_affine_residual", _p(y.t), y.t.stride(0), _p(scale), _p(shift), ans, _p(x.t), x.t.stride(0), _p(x.t2),
+             x.t2.stride(0) if x.t2 is not None else 0, x.c1 if x.t2 is not None else (1 << 30), _p(out), out.stride(0),
+             y.n, y.h * y.w, y.c, _stream())
+    return Act(out, y.n, y.h, y.w)
+
+
+def gn_adagn_bwd(dout, y, z, n, hw, gamma, beta, mod, mean, rstd, dgamma, dbeta, groups=32):
+    """Returns (dz [rows, C], dmod [n, C] or None)."""
+    C_ = y.shape[1]
+    dev = y.device
+    dz = torch.empty((n * hw, C_), dtype=torch.float32, device=dev)
+    dmod = torch.empty((n, C_), dtype=torch.float32, device=dev) if mod is not None else None
+    ws = torch.empty((n * C_ * 5,), dtype=torch.float32, device=dev)
+    mns = 0 if (mod is None or mod.shape[0] == 1) else mod.stride(0)
+    lib.call("sdm_gn_adagn_bwd", _p(dout), dout.stride(0), _p(y), y.stride(0), _p(z), z.stride(0) if z is not None else 0,
+             n, hw, C_, groups, _p(gamma), _p(beta), _p(mod), mns, _p(mean), _p(rstd), _p(dz), dz.stride(0), _p(dmod),
+             _p(dgamma), _p(dbeta), _p(ws), _stream())
+    return dz, dmod
+
+
+def sinusoid(t, freq, D):
+    out = torch.empty((t.shape[0], D), dtype=torch.float32, device=freq.device)
+    lib.call("sdm_sinusoid", _p(t), _p(freq), t.shape[0], D, _p(out), _stream())
+    return out
+
+
+def linear_small(x, W, b, act=ACT_NONE, add=None, save_z=False):
+    M, K = x.shape
+    O = W.shape[0]
+    out = torch.empty((M, O), dtype=torch.float32, device=x.device)
+    z = torch.empty_like(out) if save_z else None
+    lib.call("sdm_linear_small", _p(x), x.stride(0), _p(W), _p(b), _p(add), _p(out), out.stride(0), _p(z), M, K, O, act,
+             _stream())
+    return (out, z) if save_z else out
+
+
+def linear_small_bwd(dy, x, W, dx=None, dx_accumulate=False, dW=None, db=None):
+    M, O = dy.shape
+    K = W.shape[1]
+    lib.call("sdm_linear_small_bwd", _p(dy), dy.stride(0), _p(x), x.stride(0) if x is not None else 0, _p(W), _p(dx),
+             dx.stride(0) if dx is not None else 0, int(dx_accumulate), _p(dW), _p(db), M, K, O, _stream())
+
+
+def colsum(x, out, accumulate=False):
+    lib.call("sdm_colsum", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), int(accumulate), _stream())
+
+
+def silu(x):
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    lib.call("sdm_silu", _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def silu_bwd(dy, z, dx=None):
+    if dx is None:
+        dx = torch.empty_like(dy)
+    lib.call("sdm_silu_bwd", _p(dy), _p(z), _p(dx), dy.numel(), _stream())
+    return dx
+
+
+def add(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    lib.call("sdm_add", _p(a), _p(b), _p(out), a.numel(), _stream())
+    return out
+
+
+def mse(a, b, want_grad=True):
+    loss = torch.empty((1,), dtype=torch.float32, device=a.device)
+    grad = torch.empty_like(a) if want_grad else None
+    lib.call("sdm_mse", _p(a), _p(b), _p(loss), _p(grad), a.numel(), _stream())
+    return loss, grad
+
+
+def tanh_bwd(dy, y):
+    dx = torch.empty_like(dy)
+    lib.call("sdm_tanh_bwd", _p(dy), _p(y), _p(dx), dy.numel(), _stream())
+    return dx
+
+
+def q_sample(x0, eps, alpha_bar):
+    xt = torch.empty_like(x0)
+    lib.call("sdm_q_sample", _p(x0), _p(eps), _p(alpha_bar), _p(xt), x0.shape[0], x0[0].numel(), _stream())
+    return xt
+
+
+def ddpm_update(x, eps, z, coef):
+    lib.call("sdm_ddpm_update", _p(x), _p(eps), _p(z), _p(coef), x.numel(), _stream())
+
+
+def ddim_update(x, eps, coef, x0_out=None, last=False):
+    lib.call("sdm_ddim_update", _p(x), _p(eps), _p(coef), _p(x0_out), int(last), x.numel(), _stream())

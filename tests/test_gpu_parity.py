@@ -1,0 +1,355 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden
+vectors.  Everything here needs an MI355X: run with ``pytest -m gpu``.
+
+Tolerances: the north_star gate is rtol=1e-3 / atol=1e-4 fp32 on U_Net.forward; because that gate
+is loose at default-init magnitudes every forward test also asserts a relative-L2
+error <= 2e-5, and gradient tests assert relative-L2 <= 1e-4 per tensor.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+RTOL, ATOL = 1e-3, 1e-4
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from models import custom_layers
+    return custom_layers
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import unet_oracle
+    return unet_oracle
+
+
+def rows(x):      # NCHW cpu tensor -> NHWC rows on device
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * h * w, c).contiguous().cuda()
+
+
+def unrows(t, n, h, w):
+    return t.reshape(n, h, w, -1).permute(0, 3, 1, 2).contiguous().cpu()
+
+
+# ------------------------------------------------------------------------------------------------
+# contraction kernel: conv forward / data gradient / weight gradient on seeded shapes
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # kind, n, cin, cout, h, w
+    ("c3s1", 2, 32, 64, 6, 10),
+    ("c3s1", 1, 128, 128, 16, 16),
+    ("c3s1", 3, 36, 20, 5, 7),          # ragged channels (K, N not multiples of 32)
+    ("c3s1", 1, 256, 256, 4, 4),        # small-M, split-K path
+    ("c3s1", 4, 64, 96, 32, 32),        # 128x128-tile path (M=4096)
+    ("c3s2", 2, 32, 64, 8, 12),
+    ("c3s2", 1, 64, 64, 7, 9),          # odd spatial dims
+    ("ct4", 2, 64, 32, 3, 5),
+    ("ct4", 1, 128, 64, 8, 8),
+]
+
+
+def torch_conv(x, w, b, kind):
+    import torch.nn.functional as F
+    if kind == "c3s1":
+        return F.conv2d(x, w, b, padding=1)
+    if kind == "c3s2":
+        return F.conv2d(x, w, b, stride=2, padding=1)
+    return F.conv_transpose2d(x, w, b, stride=2, padding=1)
+
+
+@pytest.mark.parametrize("kind,n,cin,cout,h,w", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(dev, L, kind, n, cin, cout, h, w):
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(hash((kind, n, cin, cout, h, w)) % 2**31)
+    conv = L.TapConv(cin, cout, kind)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / (cin * 9) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+    x = torch.randn(n, cin, h, w, generator=g)
+    xw = x.clone().requires_grad_(True)
+    wref = conv.weight.detach().contiguous().clone().requires_grad_(True)
+    bref = conv.bias.detach().clone().requires_grad_(True)
+    z = torch_conv(xw, wref, bref, kind)
+    y = z * torch.sigmoid(z)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+
+    conv = conv.to(dev)
+    a = ops.Act(rows(x), n, h, w)
+    out = ops.conv_fwd(a, conv.taps(), conv.bias, kind, ops.ACT_SILU, save_z=True)
+    got = unrows(out.t, n, out.h, out.w)
+    assert rel(got, y) < 2e-5, rel(got, y)
+    assert rel(unrows(out.z, n, out.h, out.w), z) < 2e-5
+    # backward: dz = dy * silu'(z)
+    dz = ops.silu_bwd(rows(dy), out.z)
+    grads = {conv.weight: L.param_grad_like(conv.weight), conv.bias: torch.empty_like(conv.bias)}
+    dx = conv.backward(a, (out.h, out.w), dz, grads)
+    assert rel(unrows(dx, n, h, w), xw.grad) < 1e-4, rel(unrows(dx, n, h, w), xw.grad)
+    assert rel(grads[conv.weight], wref.grad) < 1e-4, rel(grads[conv.weight], wref.grad)
+    assert rel(grads[conv.bias], bref.grad) < 1e-4
+
+
+def test_conv_concat_affine_and_residual_epilogue(dev, L):
+    """Two-pointer (concat) input with the pending affine, against an explicit cat + affine on the CPU."""
+    import torch.nn.functional as F
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(3)
+    n, c1, c2, cout, h, w = 2, 32, 64, 64, 6, 10
+    conv = L.TapConv(c1 + c2, cout, "c3s1")
+    x1, x2 = torch.randn(n, c1, h, w, generator=g), torch.randn(n, c2, h, w, generator=g)
+    y = F.conv2d(torch.cat((x1, x2), 1), conv.weight.detach().contiguous(), conv.bias.detach(), padding=1)
+    conv = conv.to(dev)
+    a = ops.Act(rows(x1), n, h, w, t2=rows(x2))
+    out = ops.conv_fwd(a, conv.taps(), conv.bias, "c3s1", ops.ACT_NONE)
+    assert rel(unrows(out.t, n, h, w), y) < 2e-5
+    # affine-on-load: padding must stay zero AFTER the affine
+    conv2 = L.TapConv(c2, cout, "c3s1")
+    sc, sh = torch.randn(n, c2, generator=g), torch.randn(n, c2, generator=g)
+    xa = x2 * sc[:, :, None, None] + sh[:, :, None, None]
+    y2 = F.conv2d(xa, conv2.weight.detach().contiguous(), conv2.bias.detach(), padding=1)
+    conv2 = conv2.to(dev)
+    a2 = ops.Act(rows(x2), n, h, w, scale=sc.cuda(), shift=sh.cuda())
+    out2 = ops.conv_fwd(a2, conv2.taps(), conv2.bias, "c3s1", ops.ACT_NONE)
+    assert rel(unrows(out2.t, n, h, w), y2) < 2e-5
+    # broadcast (batch-1) affine table
+    a3 = ops.Act(rows(x2), n, h, w, scale=sc[:1].cuda().contiguous(), shift=sh[:1].cuda().contiguous())
+    xb = x2 * sc[:1, :, None, None] + sh[:1, :, None, None]
+    y3 = F.conv2d(xb, conv2.weight.detach().cpu().contiguous(), conv2.bias.detach().cpu(), padding=1)
+    out3 = ops.conv_fwd(a3, conv2.taps(), conv2.bias, "c3s1", ops.ACT_NONE)
+    assert rel(unrows(out3.t, n, h, w), y3) < 2e-5
+
+
+def test_linear_rows_and_small(dev):
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(5)
+    for rows_, K, O_ in ((70, 32, 96), (512, 512, 1536), (3, 10, 32), (35, 33, 17)):
+        x, W, b = torch.randn(rows_, K, generator=g), torch.randn(O_, K, generator=g) / K ** 0.5, torch.randn(O_, generator=g)
+        ref = x @ W.T + b
+        got = ops.linear_rows(x.cuda(), W.cuda(), b.cuda())
+        assert rel(got, ref) < 2e-5, (rows_, K, O_, rel(got, ref))
+        got2 = ops.linear_small(x.cuda(), W.cuda(), b.cuda())
+        assert rel(got2, ref) < 2e-5
+        gy = torch.randn(rows_, O_, generator=g)
+        dx = ops.linear_rows_dgrad(gy.cuda(), W.cuda())
+        assert rel(dx, gy @ W) < 2e-5
+        dW = torch.empty(O_, K, device="cuda")
+        ops.linear_rows_wgrad(gy.cuda(), x.cuda(), dW)
+        assert rel(dW, gy.T @ x) < 2e-5, (rows_, K, O_, rel(dW, gy.T @ x))
+
+
+# ------------------------------------------------------------------------------------------------
+# block-level goldens produced by the reference (tests/golden/blocks.npz)
+# ------------------------------------------------------------------------------------------------
+def load_block(b, tag, module):
+    sd = {k[len(tag) + 3:]: T(b[k]) for k in b.files if k.startswith(tag + "/p/")}
+    module.load_state_dict(sd, strict=True)
+    return module.cuda()
+
+
+def test_attention_block_golden(dev, L):
+    from sdm_hip import ops
+    b = np.load(os.path.join(GOLDEN, "blocks.npz"))
+    for tag, heads, dk in (("attn_h2", 2, 16), ("attn_h1", 1, None)):
+        m = load_block(b, tag, L.AttentionBlock(32, heads=heads, d_k=dk))
+        x = T(b[f"{tag}/x"])
+        y = m(x.cuda())
+        ref = T(b[f"{tag}/y"])
+        assert torch.allclose(y.cpu(), ref, rtol=RTOL, atol=ATOL), float((y.cpu() - ref).abs().max())
+        assert rel(y, ref) < 2e-5, rel(y, ref)
+        # backward
+        n, c, h, w = x.shape
+        ctx = L.RunCtx(True)
+        m.run(ctx, ops.Act(rows(x), n, h, w))
+        grads = {p: L.param_grad_like(p) for p in m.parameters()}
+        dx = m.backward(ctx, rows(T(b[f"{tag}/dy"])), grads)
+        assert rel(unrows(dx, n, h, w), T(b[f"{tag}/dx"])) < 1e-4
+        assert rel(grads[m.projection.weight], T(b[f"{tag}/dproj_w"])) < 1e-4
+        assert rel(grads[m.projection.bias], T(b[f"{tag}/dproj_b"])) < 1e-4
+        assert rel(grads[m.output.weight], T(b[f"{tag}/dout_w"])) < 1e-4
+        assert rel(grads[m.output.bias], T(b[f"{tag}/dout_b"])) < 1e-4
+
+
+def test_adagn_convblock_resblock_resample_golden(dev, L):
+    from sdm_hip import ops
+    b = np.load(os.path.join(GOLDEN, "blocks.npz"))
+    m = load_block(b, "adagn", L.AdaGN(16, 64))
+    y = m(T(b["adagn/x"]).cuda(), T(b["adagn/emb"]).cuda())
+    assert rel(y, T(b["adagn/y"])) < 2e-5
+    y1 = m(T(b["adagn/x"]).cuda(), T(b["adagn/emb"])[:1].cuda())
+    assert rel(y1, T(b["adagn/y_b1"])) < 2e-5
+
+    m = load_block(b, "convblock", L.UNet_ConvBlock(32, 64, use_activation=True, emb_dim=16))
+    y = m(T(b["convblock/x"]).cuda(), T(b["convblock/emb"]).cuda())
+    assert rel(y, T(b["convblock/y"])) < 2e-5
+    # backward of conv -> SiLU -> AdaGN
+    x = T(b["convblock/x"])
+    n, c, h, w = x.shape
+    ctx = L.RunCtx(True)
+    ctx.emb = T(b["convblock/emb"]).cuda()
+    ctx.demb = torch.zeros_like(ctx.emb)
+    m.run(ctx, ops.Act(rows(x), n, h, w), ctx.emb)
+    grads = {p: L.param_grad_like(p) for p in m.parameters()}
+    dx = m.backward(ctx, rows(T(b["convblock/dy"])), grads)
+    assert rel(unrows(dx, n, h, w), T(b["convblock/dx"])) < 1e-4, rel(unrows(dx, n, h, w), T(b["convblock/dx"]))
+    assert rel(grads[m.conv_layer.conv.weight], T(b["convblock/dw"])) < 1e-4
+    assert rel(grads[m.conv_layer.conv.bias], T(b["convblock/db"])) < 1e-4
+
+    m = load_block(b, "resblock", L.ResidualBlock(32, 32, emb_dim=16))
+    y = m(T(b["resblock/x"]).cuda(), T(b["resblock/emb"]).cuda())
+    assert rel(y, T(b["resblock/y"])) < 2e-5
+    x = T(b["resblock/x"])
+    n, c, h, w = x.shape
+    ctx = L.RunCtx(True)
+    ctx.emb = T(b["resblock/emb"]).cuda()
+    ctx.demb = torch.zeros_like(ctx.emb)
+    m.run(ctx, ops.Act(rows(x), n, h, w), ctx.emb)
+    grads = {p: L.param_grad_like(p) for p in m.parameters()}
+    dx = m.backward(ctx, rows(T(b["resblock/dy"])), grads)
+    assert rel(unrows(dx, n, h, w), T(b["resblock/dx"])) < 1e-4
+
+    for tag, mod in (("down", L.DownsampleBlock(32, 64)), ("up", L.UpsampleBlock(64, 32))):
+        m = load_block(b, tag, mod)
+        y = m(T(b[f"{tag}/x"]).cuda())
+        assert rel(y, T(b[f"{tag}/y"])) < 2e-5, tag
+
+    # AdaGN backward on its own (dx, demb, y_scale and GroupNorm affine gradients)
+    m = load_block(b, "adagn", L.AdaGN(16, 64))
+    x = T(b["adagn/x"])
+    n, c, h, w = x.shape
+    ctx = L.RunCtx(True)
+    ctx.emb = T(b["adagn/emb"]).cuda()
+    ctx.demb = torch.zeros_like(ctx.emb)
+    ya = ops.Act(rows(x), n, h, w)
+    mod = m.modulation(ctx.emb)
+    _, _, mean, rstd = m.fold(ya, mod)
+    grads = {p: L.param_grad_like(p) for p in m.parameters()}
+    dz = m.backward(ctx, rows(T(b["adagn/dy"])), ya, mod, mean, rstd, grads)     # ya.z is None -> dz == dx
+    assert rel(unrows(dz, n, h, w), T(b["adagn/dx"])) < 1e-4
+    assert rel(ctx.demb, T(b["adagn/demb"])) < 1e-4
+    assert rel(grads[m.y_scale.weight], T(b["adagn/dys_w"])) < 1e-4
+    assert rel(grads[m.y_scale.bias], T(b["adagn/dys_b"])) < 1e-4
+    assert rel(grads[m.group_norm.weight], T(b["adagn/dgn_w"])) < 1e-4
+    assert rel(grads[m.group_norm.bias], T(b["adagn/dgn_b"])) < 1e-4
+
+
+def test_embedding_golden(dev, L):
+    b = np.load(os.path.join(GOLDEN, "blocks.npz"))
+    for tag, cd in (("emb_t", None), ("emb_tc", 5)):
+        m = load_block(b, tag, L.ConditionalEmbedding(32, cd))
+        y = m(T(b[f"{tag}/t"]).cuda(), T(b[f"{tag}/cond"]).cuda() if cd else None)
+        assert rel(y, T(b[f"{tag}/y"])) < 2e-5, (tag, rel(y, T(b[f"{tag}/y"])))
+
+
+# ------------------------------------------------------------------------------------------------
+# whole-model goldens (reference outputs) and gradients
+# ------------------------------------------------------------------------------------------------
+CASES = ["narrow_cond", "narrow_gain", "deep_uncond", "sr_recon", "no_emb"]
+
+
+def build(case, O):
+    from models.U_Net import U_Net
+    g = np.load(os.path.join(GOLDEN, f"model_{case}.npz"))
+    cfg = json.loads(str(g["cfg"]))
+    net = U_Net(**cfg)
+    net.load_state_dict(O.seeded_params(cfg, seed=3, gain=float(g["gain"])), strict=True)
+    return g, cfg, net.cuda()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_unet_forward_golden(dev, O, case):
+    g, cfg, net = build(case, O)
+    net.eval()
+    x, t = T(g["x"]).cuda(), T(g["t"]).cuda()
+    cond = T(g["cond"]).cuda() if "cond" in g.files else None
+    with torch.no_grad():
+        y = net(x, t if cfg["time_dim"] is not None else None, cond)
+    ref = T(g["y"])
+    assert y.shape == ref.shape
+    assert torch.allclose(y.cpu(), ref, rtol=RTOL, atol=ATOL), float((y.cpu() - ref).abs().max())
+    assert rel(y, ref) < 2e-5, rel(y, ref)
+    if cfg["time_dim"] is not None:       # sampler convention: t of shape (1,), labels of shape (cond_dim,)
+        with torch.no_grad():
+            yb = net(x, t[:1], cond[0] if cond is not None else None)
+        assert rel(yb, T(g["y_b1"])) < 2e-5
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_unet_grads_golden(dev, O, case):
+    g, cfg, net = build(case, O)
+    net.train()
+    x, t = T(g["x"]).cuda(), T(g["t"]).cuda()
+    cond = T(g["cond"]).cuda() if "cond" in g.files else None
+    y = net(x, t if cfg["time_dim"] is not None else None, cond)
+    loss = torch.nn.functional.mse_loss(y, T(g["target"]).cuda())
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    dead = json.loads(str(g["dead"]))
+    bad = []
+    for k, p in net.named_parameters():
+        if k in dead:
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None, k
+        gr = p.grad.detach().double().cpu().contiguous().flatten()
+        ref = T(g[f"gval/{k}"]).double()
+        got = gr[T(g[f"gidx/{k}"])]
+        nrm = float(g[f"gstat/{k}"][2])
+        err_n = abs(float(gr.norm()) - nrm) / (nrm + 1e-30)
+        err_s = float((got - ref).norm() / (ref.norm() + 1e-30))
+        if err_n > 1e-4 or err_s > 2e-4:
+            bad.append((k, err_n, err_s))
+    assert not bad, bad[:10]
+
+
+def test_unet_loss_and_grads_api_matches_autograd(dev, O):
+    g, cfg, net = build("narrow_cond", O)
+    x, t, cond, tgt = T(g["x"]).cuda(), T(g["t"]).cuda(), T(g["cond"]).cuda(), T(g["target"]).cuda()
+    loss, grads = net.loss_and_grads(x, t, cond, tgt)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    y = net(x, t, cond)
+    torch.nn.functional.mse_loss(y, tgt).backward()
+    for _, p in net.live_parameters():
+        assert rel(grads[p], p.grad) < 1e-5
+
+
+def test_standard_architecture_vs_oracle(dev, O):
+    """Full-size 127 M-parameter standard architecture at 64x64: too large for a fixture, so the
+    comparator is the pinned CPU oracle on the same seeded weights/inputs."""
+    from models.U_Net import U_Net
+    cfg = dict(O.STANDARD_CFG)
+    torch.manual_seed(0)
+    net = U_Net(**cfg)
+    P = {k: v.detach().clone().contiguous() for k, v in net.state_dict().items()}
+    net = net.cuda().eval()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(2, 3, 64, 64, generator=g)
+    t = torch.tensor([753, 12])
+    with torch.no_grad():
+        ref = O.unet_forward(P, cfg, x, t)
+        y = net(x.cuda(), t.cuda())
+    assert torch.allclose(y.cpu(), ref, rtol=RTOL, atol=ATOL), float((y.cpu() - ref).abs().max())
+    assert rel(y, ref) < 2e-5, rel(y, ref)
