@@ -49,6 +49,14 @@ int sdm_device_info(int* out4);
 /* sizeof the ABI structs (0 igemm desc, 1 wgrad desc, 2 rows, 3 linear job, 4 adam job) so a binding can assert its layout */
 size_t sdm_struct_size(int which);
 
+/* Per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg; not capturable, so
+ * keep it off inside hipGraph capture).  Classes: 0 igemm 128x128, 1 igemm 64x64, 2 igemm 32x128,
+ * 3 wgrad 128x128, 4 wgrad 64x64.  sdm_prof_begin(cap) arms it for up to cap launches; sdm_prof_end
+ * synchronises the recorded events and fills, per class c: ms[c], launches[c], flops[c] (algorithmic 2*M*N*K*taps). */
+#define SDM_PROF_CLASSES 5
+int sdm_prof_begin(int capacity);
+int sdm_prof_end(double* ms, long long* launches, double* flops);
+
 /* A logical matrix of "pixel rows x channels", optionally the channel-concat of two
  * tensors (U_Net.py:168 torch.cat) and optionally carrying a pending per-(image,channel)
  * affine v*scale+shift (the deferred GroupNorm+AdaGN of custom_layers.py:35-45) that is
@@ -240,9 +248,17 @@ int sdm_q_sample(const float* x0, const float* eps, const float* alpha_bar, floa
  * {1/sqrt(alpha_t), (1-alpha_t)/sqrt(1-abar_t), sigma_t} (device-resident so a captured graph can be replayed
  * with new coefficients); z may be NULL (last step). x is updated in place. */
 int sdm_ddpm_update(float* x, const float* eps, const float* z, const float* coef, size_t n, sdm_stream_t s);
-/* DDIM update (diffusion_sampling_algorithms.py:111-136, eta=0): coef = {1/sqrt(abar_t), sqrt(1-abar_t),
- * sqrt(abar_tm1), sqrt(1-abar_tm1)}; x0_out optional. */
-int sdm_ddim_update(float* x, const float* eps, const float* coef, float* x0_out, int last, size_t n, sdm_stream_t s);
+/* DDIM update (diffusion_sampling_algorithms.py:111-136, eta=0): coef (DEVICE, 5 floats) = {1/sqrt(abar_t),
+ * sqrt(1-abar_t), sqrt(abar_tm1), sqrt(1-abar_tm1), update_flag}.  x0_out (optional) receives the x0 estimate;
+ * x is advanced to x_{t-1} only when update_flag != 0 (the reference skips the update on the last step). */
+int sdm_ddim_update(float* x, const float* eps, const float* coef, float* x0_out, size_t n, sdm_stream_t s);
+
+/* Step-table cursor for a hipGraph-captured sampling step: t_cur[0] = t_table[*cursor];
+ * coef_cur[0..ncoef) = coef_table[*cursor][0..ncoef); ++*cursor (saturating at nsteps-1).  With it the captured
+ * graph (advance -> U-Net forward -> update) is parameter-free and is simply replayed once per denoise step
+ * (the python for-loops of diffusion_sampling_algorithms.py:21-63 and :91-145). */
+int sdm_step_advance(int* cursor, const int64_t* t_table, const float* coef_table, int ncoef, int nsteps,
+                     int64_t* t_cur, float* coef_cur, sdm_stream_t s);
 
 /* Fused multi-tensor Adam (torch.optim.Adam defaults, train_diffusion.py:214-217): jobs is a DEVICE array. */
 typedef struct sdm_adam_job { float* p; const float* g; float* m; float* v; int64_t n; } sdm_adam_job;

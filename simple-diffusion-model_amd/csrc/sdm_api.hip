@@ -40,3 +40,60 @@ extern "C" size_t sdm_struct_size(int which) {
     default: return 0;
   }
 }
+
+// ---- per-launch event timing ----------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+std::vector<ProfRec> g_prof;
+int g_prof_cap = 0;
+bool g_prof_armed = false;
+hipEvent_t g_pending = nullptr;
+}  // namespace
+
+bool sdm_prof_on() { return g_prof_armed && (int)g_prof.size() < g_prof_cap; }
+void sdm_prof_pre(hipStream_t st) {
+  if (!sdm_prof_on()) return;
+  if (hipEventCreate(&g_pending) != hipSuccess) { g_pending = nullptr; return; }
+  (void)hipEventRecord(g_pending, st);
+}
+void sdm_prof_post(hipStream_t st, int cls, double flops) {
+  if (!g_pending) return;
+  ProfRec r;
+  r.a = g_pending;
+  g_pending = nullptr;
+  if (hipEventCreate(&r.b) != hipSuccess) { (void)hipEventDestroy(r.a); return; }
+  (void)hipEventRecord(r.b, st);
+  r.cls = cls;
+  r.flops = flops;
+  g_prof.push_back(r);
+}
+
+extern "C" int sdm_prof_begin(int capacity) {
+  SDM_CHECK_ARG(capacity > 0, "prof_begin: capacity");
+  for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof.clear();
+  g_prof.reserve(capacity);
+  g_prof_cap = capacity;
+  g_prof_armed = true;
+  return SDM_OK;
+}
+
+extern "C" int sdm_prof_end(double* ms, long long* launches, double* flops) {
+  SDM_CHECK_ARG(ms && launches && flops, "prof_end: null");
+  g_prof_armed = false;
+  for (int c = 0; c < SDM_PROF_CLASSES; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; }
+  for (auto& r : g_prof) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return sdm_set_error(SDM_ERR_LAUNCH, "prof_end: event sync failed");
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.cls >= 0 && r.cls < SDM_PROF_CLASSES) {
+      ms[r.cls] += t;
+      launches[r.cls] += 1;
+      flops[r.cls] += r.flops;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  return SDM_OK;
+}

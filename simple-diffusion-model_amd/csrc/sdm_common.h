@@ -59,3 +59,8 @@ __device__ __forceinline__ float wave_max(float v) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- optional per-launch event timing (sdm_prof_begin / sdm_prof_end) ----
+bool sdm_prof_on();
+void sdm_prof_pre(hipStream_t st);
+void sdm_prof_post(hipStream_t st, int cls, double flops);

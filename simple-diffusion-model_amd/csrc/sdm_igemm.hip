@@ -272,7 +272,11 @@ static int launch_igemm(const IgemmLaunch& L, int ntm, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(ntm * L.ntn, L.d.nphase * L.splitk, L.d.batch);
+  double taps = 0;
+  for (int p = 0; p < L.d.nphase; ++p) taps += L.d.ntaps[p];
+  sdm_prof_pre(st);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, L);
+  sdm_prof_post(st, BM == 128 ? 0 : (BM == 64 ? 1 : 2), 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
   SDM_CHECK_LAUNCH("igemm");
   return SDM_OK;
 }
@@ -538,7 +542,15 @@ template <int BT, int WM, int WN>
 static int launch_wgrad(const WgradLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = 4 * BK * BT * sizeof(float);
   dim3 grid(ntm * L.ntn, L.d.ntaps * L.splitk, L.d.batch);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<BT, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  sdm_prof_pre(st);
   hipLaunchKernelGGL((wgrad_kernel<BT, WM, WN>), grid, dim3(256), lds, st, L);
+  sdm_prof_post(st, BT == 128 ? 3 : 4,
+                2.0 * L.d.M * L.d.N * (double)L.d.images * L.d.Hk * L.d.Wk * L.d.ntaps * L.d.batch);
   SDM_CHECK_LAUNCH("wgrad");
   return SDM_OK;
 }

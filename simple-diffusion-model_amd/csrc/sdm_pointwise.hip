@@ -815,20 +815,38 @@ extern "C" int sdm_ddpm_update(float* x, const float* eps, const float* z, const
   return SDM_OK;
 }
 
-__global__ void ddim_update_kernel(float* x, const float* eps, const float* coef, float* x0_out, int last, size_t n) {
+__global__ void ddim_update_kernel(float* x, const float* eps, const float* coef, float* x0_out, size_t n) {
   const float inv = coef[0], sq1m = coef[1], sa1 = coef[2], sb1 = coef[3];
+  const bool upd = coef[4] != 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float e = eps[i];
     const float x0 = inv * (x[i] - sq1m * e);
     if (x0_out) x0_out[i] = x0;
-    if (!last) x[i] = sa1 * x0 + sb1 * e;
+    if (upd) x[i] = sa1 * x0 + sb1 * e;
   }
 }
-extern "C" int sdm_ddim_update(float* x, const float* eps, const float* coef, float* x0_out, int last, size_t n,
-                               sdm_stream_t s) {
+extern "C" int sdm_ddim_update(float* x, const float* eps, const float* coef, float* x0_out, size_t n, sdm_stream_t s) {
   SDM_CHECK_ARG(x && eps && coef && n > 0, "ddim_update: bad args");
-  hipLaunchKernelGGL(ddim_update_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, eps, coef, x0_out, last, n);
+  hipLaunchKernelGGL(ddim_update_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, eps, coef, x0_out, n);
   SDM_CHECK_LAUNCH("ddim_update");
+  return SDM_OK;
+}
+
+__global__ void step_advance_kernel(int* cursor, const int64_t* t_table, const float* coef_table, int ncoef, int nsteps,
+                                    int64_t* t_cur, float* coef_cur) {
+  const int c = *cursor;
+  if (threadIdx.x == 0) t_cur[0] = t_table[c];
+  if (threadIdx.x < ncoef) coef_cur[threadIdx.x] = coef_table[(long long)c * ncoef + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) *cursor = c + 1 < nsteps ? c + 1 : nsteps - 1;
+}
+extern "C" int sdm_step_advance(int* cursor, const int64_t* t_table, const float* coef_table, int ncoef, int nsteps,
+                                int64_t* t_cur, float* coef_cur, sdm_stream_t s) {
+  SDM_CHECK_ARG(cursor && t_table && coef_table && t_cur && coef_cur && ncoef > 0 && ncoef <= 64 && nsteps > 0,
+                "step_advance: bad args");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, cursor, t_table, coef_table, ncoef, nsteps,
+                     t_cur, coef_cur);
+  SDM_CHECK_LAUNCH("step_advance");
   return SDM_OK;
 }
 

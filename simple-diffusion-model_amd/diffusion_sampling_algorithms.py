@@ -1,0 +1,180 @@
+"""DDPM / DDIM / cold-diffusion samplers — drop-in for the reference's diffusion_sampling_algorithms.py
+(same function names and arguments, :5-14, :66-76, :150-161).
+
+The reference runs a Python loop of T iterations, each with a U-Net call, ~10 elementwise torch ops and a
+host->device copy of t.  Here ONE denoise step — [step-table cursor -> U-Net forward -> fused update] — is
+captured as a hipGraph and replayed T times: the per-step timestep and update coefficients are read from
+device-resident tables through a cursor the graph itself advances, so a replay needs no host work.
+Coefficient tables are computed with the reference's own float32 expressions.
+
+Extra keyword-only arguments (not in the reference): ``noise`` injects the per-step z tensors (trajectory
+parity tests; GPU and CPU generators differ), ``use_graph`` forces/disables hipGraph capture.
+"""
+import os
+
+import torch
+
+from sdm_hip import lib, ops
+from utils.utils import printProgressBar
+
+
+def _use_graph(flag):
+    if flag is not None:
+        return flag
+    return os.environ.get("SDM_HIPGRAPH", "1") != "0"
+
+
+class _StepRunner:
+    """Owns the static buffers of one sampling run and replays the captured step."""
+
+    def __init__(self, net, x_t, t_steps, coef, cond_img, labels, noise, use_graph):
+        dev = x_t.device
+        self.net, self.cond_img, self.labels, self.noise = net, cond_img, labels, noise
+        self.x = x_t.detach().to(torch.float32).contiguous().clone()
+        self.nsteps, self.ncoef = len(t_steps), coef.shape[1]
+        self.t_table = torch.tensor(t_steps, dtype=torch.int64, device=dev)
+        self.coef_table = coef.to(torch.float32).contiguous().to(dev)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.t_cur = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.coef_cur = torch.zeros(self.ncoef, dtype=torch.float32, device=dev)
+        self.graph = None
+        self.body = None
+        self.use_graph = use_graph
+
+    def advance(self):
+        lib.call("sdm_step_advance", self.cursor.data_ptr(), self.t_table.data_ptr(), self.coef_table.data_ptr(), self.ncoef,
+                 self.nsteps, self.t_cur.data_ptr(), self.coef_cur.data_ptr(), ops._stream())
+
+    def eps(self):
+        xin = self.x if self.cond_img is None else torch.cat((self.x, self.cond_img), dim=1)
+        return self.net(xin, self.t_cur, self.labels)
+
+    def z(self):
+        if self.noise is None:
+            return torch.randn(self.x.shape, device=self.x.device)
+        idx = (self.cursor - 1).clamp_(min=0).to(torch.int64)        # cursor already advanced for this step
+        return self.noise.index_select(0, idx)[0]
+
+    def run(self, body, on_step):
+        if self.use_graph:
+            x0 = self.x.clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):                               # warm-up: sizes workspaces, sets kernel attributes
+                body()
+            torch.cuda.current_stream().wait_stream(s)
+            self.x.copy_(x0)
+            self.cursor.zero_()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                body()
+            self.x.copy_(x0)
+            self.cursor.zero_()
+            for i in range(self.nsteps):
+                self.graph.replay()
+                on_step(i)
+        else:
+            for i in range(self.nsteps):
+                body()
+                on_step(i)
+
+
+def _require_cuda(x_t):
+    if not x_t.is_cuda:
+        raise RuntimeError("sampling runs on the MI355X: pass CUDA tensors / --device cuda")
+
+
+def ddpm_sampling(diffusion_net, noise_degradation, x_t, min_noise=1, max_noise=1_000, cond_img=None,
+                  labels_tensor=None, device="cpu", log=print, *, noise=None, use_graph=None):
+    _require_cuda(x_t)
+    dev = x_t.device
+    diffusion_net.eval()
+    steps = list(range(max_noise, min_noise - 1, -1))
+    beta, alpha, abar = noise_degradation.get_timestep_params(torch.tensor(steps))      # float32, host tables
+    beta, alpha, abar = beta.cpu(), alpha.cpu(), abar.cpu()
+    sigma = beta ** 0.5
+    sigma = torch.where(torch.tensor(steps) > 1, sigma, torch.zeros_like(sigma))       # z = 0 when noise_step <= 1
+    coef = torch.stack((1 / (alpha ** 0.5), (1 - alpha) / ((1 - abar) ** 0.5), sigma), dim=1)
+    if cond_img is not None:
+        cond_img = cond_img.to(dev)
+    if labels_tensor is not None:
+        labels_tensor = labels_tensor.to(dev)
+    if noise is not None:
+        noise = noise.to(dev).float().contiguous()
+    r = _StepRunner(diffusion_net, x_t, steps, coef, cond_img, labels_tensor, noise, _use_graph(use_graph))
+
+    def body():
+        r.advance()
+        e = r.eps()
+        ops.ddpm_update(r.x, e, r.z(), r.coef_cur)
+
+    def on_step(i):
+        printProgressBar(iteration=i, total=max_noise - min_noise, prefix='Iterations:', suffix='Complete', length=50, log=log)
+
+    with torch.no_grad():
+        r.run(body, on_step)
+    return r.x
+
+
+def ddim_sampling(diffusion_net, noise_degradation, x_t, min_noise=1, max_noise=1_000, cond_img=None,
+                  labels_tensor=None, ddim_step_size=10, device="cpu", log=print, *, use_graph=None):
+    _require_cuda(x_t)
+    dev = x_t.device
+    diffusion_net.eval()
+    steps = list(range(max_noise, min_noise - 1, -ddim_step_size))
+    if min_noise not in steps:
+        steps = steps + [min_noise]
+    abar = noise_degradation.get_timestep_params(torch.tensor(steps))[2].cpu()
+    abar_next = torch.cat((abar[1:], abar[-1:]))                     # last entry unused (no update after the last step)
+    upd = torch.ones_like(abar)
+    upd[-1] = 0.0                                                    # the reference leaves x_t alone on the last step
+    # eta = 0 (hard-coded in the reference, :86) -> sigma = 0
+    coef = torch.stack((1 / abar ** 0.5, (1 - abar) ** 0.5, abar_next ** 0.5, (1 - abar_next - 0.0) ** 0.5, upd), dim=1)
+    if cond_img is not None:
+        cond_img = cond_img.to(dev)
+    if labels_tensor is not None:
+        labels_tensor = labels_tensor.to(dev)
+    r = _StepRunner(diffusion_net, x_t, steps, coef, cond_img, labels_tensor, None, _use_graph(use_graph))
+    x0 = torch.empty_like(r.x)
+
+    def body():
+        r.advance()
+        ops.ddim_update(r.x, r.eps(), r.coef_cur, x0_out=x0)
+
+    def on_step(i):
+        printProgressBar(iteration=max_noise - steps[i], total=max_noise - min_noise, prefix='Iterations:',
+                         suffix='Complete', length=50, log=log)
+
+    with torch.no_grad():
+        r.run(body, on_step)
+    return x0 if steps[-1] == 1 else r.x
+
+
+def cold_diffusion_sampling(diffusion_net, noise_degradation, x_t, noise, min_noise=1, max_noise=1_000, cond_img=None,
+                            labels_tensor=None, skip_step_size=10, device="cpu", log=print):
+    """x0-prediction sampler of the SR path (reference :150-217): x_t <- x_t - D(x0_hat, t) + D(x0_hat, t-1)."""
+    _require_cuda(x_t)
+    dev = x_t.device
+    diffusion_net.eval()
+    steps = list(range(max_noise, min_noise - 1, -skip_step_size))
+    if min_noise not in steps:
+        steps = steps + [min_noise]
+    if cond_img is not None:
+        cond_img = cond_img.to(dev)
+    if labels_tensor is not None:
+        labels_tensor = labels_tensor.to(dev)
+    x_t = x_t.detach().float().contiguous().clone()
+    noise = noise.to(dev).float().contiguous()
+    with torch.no_grad():
+        for count, s in enumerate(steps):
+            t = torch.tensor([s], device=dev)
+            xin = x_t if cond_img is None else torch.cat((x_t, cond_img), dim=1)
+            x0_hat = diffusion_net(xin, t, labels_tensor)
+            if count < len(steps) - 1:
+                tm1 = torch.tensor([steps[count + 1]], device=dev)
+                x_t_hat = noise_degradation(img=x0_hat, steps=t, eps=noise)
+                x_tm1_hat = noise_degradation(img=x0_hat, steps=tm1, eps=noise)
+                x_t = x_t - x_t_hat + x_tm1_hat
+                printProgressBar(iteration=max_noise - s, total=max_noise - min_noise, prefix='Iterations:',
+                                 suffix='Complete', length=50, log=log)
+    return x0_hat

