@@ -36,8 +36,13 @@ PEAK_FP32_MFMA_TFLOPS = 157.3                    # MI355X_MICROARCH.md: v_mfma_f
 def cpu_baseline(batch, res, steps=3):
     """Oracle (plain torch CPU ops == the reference's CPU path) training steps on the host cores."""
     from oracle import unet_oracle as O
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))       # a 1-GPU box gives this job a 16-CPU share; more threads only oversubscribe
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: os.cpu_count={os.cpu_count()} affinity={avail} threads={cores}", file=sys.stderr, flush=True)
     torch.manual_seed(0)
     from models.U_Net import U_Net
     net = U_Net(**STANDARD)
@@ -48,7 +53,11 @@ def cpu_baseline(batch, res, steps=3):
     x0 = torch.randn(batch, 3, res, res, generator=g)
     eps = torch.randn(batch, 3, res, res, generator=g)
     t = torch.randint(1, 1000, (batch,), generator=g)
+    tw = time.perf_counter()
     tr.step(x0, t, eps)                                        # warm-up
+    tw = time.perf_counter() - tw
+    print(f"[bench] cpu_baseline: warm-up step {tw:.2f}s", file=sys.stderr, flush=True)
+    steps = max(1, min(steps, int(20.0 / max(tw, 1e-3))))      # bound the sample to ~20 s of CPU work
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.step(x0, t, eps)
@@ -112,6 +121,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     loss_v = float(loss)
+    print(f"[bench] rank {rank}: {args.steps} train steps in {dt:.3f}s", file=sys.stderr, flush=True)
 
     # ---- sampling rate of the hipGraph-captured DDPM step (rank 0 only, replicas need no collective)
     sample_rate = None
@@ -124,6 +134,7 @@ def main():
         S.ddpm_sampling(net, sched, xT, 1, args.sample_steps, device="cuda", log=quiet)
         torch.cuda.synchronize()
         sample_rate = args.sample_steps / (time.perf_counter() - ts)     # includes one capture; amortised over T
+        print(f"[bench] sampling: {sample_rate:.1f} steps/s", file=sys.stderr, flush=True)
 
     if rank != 0:
         if world > 1:
