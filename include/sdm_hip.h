@@ -51,9 +51,9 @@ size_t sdm_struct_size(int which);
 
 /* Per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg; not capturable, so
  * keep it off inside hipGraph capture).  Classes: 0 igemm 128x128, 1 igemm 64x64, 2 igemm 32x128,
- * 3 wgrad 128x128, 4 wgrad 64x64.  sdm_prof_begin(cap) arms it for up to cap launches; sdm_prof_end
+ * 3 wgrad 128x128, 4 wgrad 64x64, 5 igemm 128x64.  sdm_prof_begin(cap) arms it for up to cap launches; sdm_prof_end
  * synchronises the recorded events and fills, per class c: ms[c], launches[c], flops[c] (algorithmic 2*M*N*K*taps). */
-#define SDM_PROF_CLASSES 5
+#define SDM_PROF_CLASSES 6
 int sdm_prof_begin(int capacity);
 int sdm_prof_end(double* ms, long long* launches, double* flops);
 
@@ -127,7 +127,9 @@ typedef struct sdm_igemm_desc {
   int64_t ldz;
   int dact_ncols;         /* silu'(z) is applied to output columns [0, dact_ncols); 0 = all N */
 
-  float* ws;              /* split-K scratch: M_out_rows*N floats, used only when the library splits K */
+  float* ws;              /* split-K scratch: M_out_rows*N floats, used only when the library splits K.
+                             CONTRACT: the caller hands it over zero-filled once; every call leaves the part it
+                             touched zero-filled again (the finishing pass clears what it reads) */
   size_t ws_bytes;
 } sdm_igemm_desc;
 
@@ -158,7 +160,8 @@ typedef struct sdm_wgrad_desc {
   int64_t ldw, w_tap_stride;
   int64_t w_bs0, w_bs1;
   float alpha;
-  int accumulate; /* 0: dw is overwritten (library zeroes it first if it splits K); 1: added into */
+  int accumulate; /* 0: dw is overwritten (library zeroes it first if it splits K); 1: added into;
+                     2: dw is known to be all zeros already (no memset; result = the contraction) */
 } sdm_wgrad_desc;
 
 int sdm_wgrad(const sdm_wgrad_desc* d, sdm_stream_t stream);
@@ -222,8 +225,8 @@ int sdm_linear_multi(const float* x, int64_t ldx, int M, int K, const sdm_linear
                      int maxO, sdm_stream_t s);
 
 /* backward of a small-batch linear given dy (already multiplied by act'):
- *   dx[m][k] (=|+=) sum_o dy[m][o] w[o][k] ; dw[o][k] += sum_m dy[m][o] x[m][k] ; db[o] += sum_m dy[m][o]
- * dx / dw may be NULL to skip. */
+ *   dx[m][k] += sum_o dy[m][o] w[o][k] ; dw[o][k] += sum_m dy[m][o] x[m][k] ; db[o] += sum_m dy[m][o]
+ * (all three ACCUMULATE: hand in zero-filled buffers for plain results).  dx / dw may be NULL to skip. */
 int sdm_linear_small_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* w, float* dx,
                          int64_t lddx, int dx_accumulate, float* dw, float* db, int M, int K, int O, sdm_stream_t s);
 

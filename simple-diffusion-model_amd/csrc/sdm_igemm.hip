@@ -16,10 +16,13 @@
 
 struct IgemmLaunch {
   sdm_igemm_desc d;
-  int splitk, vecA, vecB, ntn, kchunks;
+  int splitk, ntn, kchunks;
 };
 
-template <int BM, int BN, int WM, int WN, bool BKM>
+// One K-step = (tap, 32-channel chunk).  Per-tap state (row pointers, validity) is rebuilt only when the tap
+// changes; inside a tap the loads are pointer + running channel offset, so the steady-state loop is
+// [LDS store | barrier | issue next loads | 4 x (fragment reads + MFMAs)].
+template <int BM, int BN, int WM, int WN, bool BKM, bool VEC>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
   const sdm_igemm_desc& d = L.d;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -43,7 +46,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
   const float* a1 = d.a.p1;
   const float* bw = d.b + b0 * d.b_bs0 + b1 * d.b_bs1;
   const int HtWt = d.Ht * d.Wt;
-  const int K = d.K, N = d.N;
+  const int K = d.K, N = d.N, csplit = d.a.csplit;
+  const bool affine = d.a.scale != nullptr;
+  const int cc4 = 4 * (tid & 7);           // channel offset of this thread's 16-byte chunk inside a K-step
+  const int arow = tid >> 3;               // tile row (A, and B when K-contiguous) handled in pass 0
 
   for (int r = tid; r < BM; r += 256) {
     int m = m0 + r;
@@ -57,18 +63,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
     s_orow[r] = o;
   }
 
-  // per-thread A rows: r = (tid>>3) + 32*i, channel chunk = tid&7
-  int a_base[AIT], a_ys[AIT], a_xs[AIT], a_n[AIT];
+  int a_ys[AIT], a_xs[AIT], a_n[AIT];
+  long long a_base[AIT];
 #pragma unroll
   for (int i = 0; i < AIT; ++i) {
-    int m = m0 + (tid >> 3) + 32 * i;
+    int m = m0 + arow + 32 * i;
     if (m < d.M) {
       int n = m / HtWt, rem = m - n * HtWt;
       int y = rem / d.Wt, x = rem - y * d.Wt;
       a_n[i] = n;
       a_ys[i] = y * d.sstride;
       a_xs[i] = x * d.sstride;
-      a_base[i] = (n * d.a.H + a_ys[i]) * d.a.W + a_xs[i];
+      a_base[i] = ((long long)n * d.a.H + a_ys[i]) * d.a.W + a_xs[i];
     } else {
       a_n[i] = 0; a_ys[i] = -(1 << 20); a_xs[i] = 0; a_base[i] = 0;
     }
@@ -79,21 +85,49 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
   const int T = ntap * kch;
   const int it0 = (int)((long long)T * ks / L.splitk), it1 = (int)((long long)T * (ks + 1) / L.splitk);
 
-  f32x4 ra[AIT], rb[BIT];
-
-  auto load = [&](int it) {
-    const int tp = it / kch, c0 = (it - tp * kch) * BK;
+  // ---- per-tap state
+  const float* pa0[AIT];
+  const float* pa1[AIT];
+  bool aok[AIT];
+  const float* pb[BIT];
+  bool bok[BIT];
+  auto setup_tap = [&](int tp) {
     const int dy = d.tap_dy[phase][tp], dx = d.tap_dx[phase][tp];
     const float* bt = bw + (long long)d.tap_w[phase][tp] * d.b_tap_stride;
-    const int c = c0 + 4 * (tid & 7);
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+      const int sy = a_ys[i] + dy, sx = a_xs[i] + dx;
+      aok[i] = (unsigned)sy < (unsigned)d.a.H && (unsigned)sx < (unsigned)d.a.W;
+      const long long row = a_base[i] + dy * d.a.W + dx;
+      pa0[i] = a0 + row * d.a.ld0 + cc4;
+      pa1[i] = a1 + row * d.a.ld1 + (cc4 - csplit);
+    }
+    if (!BKM) {
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) {
+        const int n = n0 + arow + 32 * i;
+        bok[i] = n < N;
+        pb[i] = bt + (long long)n * d.ldb + cc4;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) {
+        const int n = n0 + 4 * (tid % CPR);
+        bok[i] = n < N;
+        pb[i] = bt + (long long)(tid / CPR + RPP * i) * d.ldb + n;
+      }
+    }
+  };
+
+  f32x4 ra[AIT], rb[BIT];
+  auto load = [&](int c0) {
+    const int c = c0 + cc4;
 #pragma unroll
     for (int i = 0; i < AIT; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int sy = a_ys[i] + dy, sx = a_xs[i] + dx;
-      if ((unsigned)sy < (unsigned)d.a.H && (unsigned)sx < (unsigned)d.a.W && c < K) {
-        const long long row = (long long)a_base[i] + dy * d.a.W + dx;
-        const float* p = (c < d.a.csplit) ? a0 + row * d.a.ld0 + c : a1 + row * d.a.ld1 + (c - d.a.csplit);
-        if (L.vecA && c + 3 < K) {
+      if (aok[i] && c < K) {
+        const float* p = (c < csplit ? pa0[i] : pa1[i]) + c0;
+        if (VEC) {
           v = *(const f32x4*)p;
         } else {
           v.x = p[0];
@@ -101,7 +135,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
           if (c + 2 < K) v.z = p[2];
           if (c + 3 < K) v.w = p[3];
         }
-        if (d.a.scale) {  // host guarantees K % 4 == 0 here
+        if (affine) {  // host guarantees K % 4 == 0 and aligned tables
           const long long so = (long long)a_n[i] * d.a.aff_nstride + c;
           const f32x4 sc = *(const f32x4*)(d.a.scale + so);
           const f32x4 sh = *(const f32x4*)(d.a.shift + so);
@@ -114,10 +148,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
 #pragma unroll
       for (int i = 0; i < BIT; ++i) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int n = n0 + (tid >> 3) + 32 * i;
-        if (n < N && c < K) {
-          const float* p = bt + (long long)n * d.ldb + c;
-          if (L.vecB && c + 3 < K) {
+        if (bok[i] && c < K) {
+          const float* p = pb[i] + c0;
+          if (VEC) {
             v = *(const f32x4*)p;
           } else {
             v.x = p[0];
@@ -129,14 +162,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
         rb[i] = v;
       }
     } else {
+      const long long koff = (long long)c0 * d.ldb;
 #pragma unroll
       for (int i = 0; i < BIT; ++i) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int kk = c0 + tid / CPR + RPP * i;
-        const int n = n0 + 4 * (tid % CPR);
-        if (kk < K && n < N) {
-          const float* p = bt + (long long)kk * d.ldb + n;
-          if (L.vecB && n + 3 < N) {
+        if (bok[i] && kk < K) {
+          const float* p = pb[i] + koff;
+          const int n = n0 + 4 * (tid % CPR);
+          if (VEC) {
             v = *(const f32x4*)p;
           } else {
             v.x = p[0];
@@ -152,16 +186,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
 
   auto store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AIT; ++i)
-      *(f32x4*)&As[buf * A_TILE + ((tid >> 3) + 32 * i) * PITCH + 4 * (tid & 7)] = ra[i];
+    for (int i = 0; i < AIT; ++i) *(f32x4*)&As[buf * A_TILE + (arow + 32 * i) * PITCH + cc4] = ra[i];
     if (!BKM) {
 #pragma unroll
-      for (int i = 0; i < BIT; ++i)
-        *(f32x4*)&Bs[buf * B_TILE + ((tid >> 3) + 32 * i) * PITCH + 4 * (tid & 7)] = rb[i];
+      for (int i = 0; i < BIT; ++i) *(f32x4*)&Bs[buf * B_TILE + (arow + 32 * i) * PITCH + cc4] = rb[i];
     } else {
 #pragma unroll
-      for (int i = 0; i < BIT; ++i)
-        *(f32x4*)&Bs[buf * B_TILE + (tid / CPR + RPP * i) * BN + 4 * (tid % CPR)] = rb[i];
+      for (int i = 0; i < BIT; ++i) *(f32x4*)&Bs[buf * B_TILE + (tid / CPR + RPP * i) * BN + 4 * (tid % CPR)] = rb[i];
     }
   };
 
@@ -173,16 +204,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  int tp = it0 / kch, kc = it0 - tp * kch;
   if (it0 < it1) {
-    load(it0);
-    store(0);
+    setup_tap(tp);
+    load(kc * BK);
   }
-  __syncthreads();
-
   for (int it = it0; it < it1; ++it) {
     const int buf = (it - it0) & 1;
-    const bool more = it + 1 < it1;
-    if (more) load(it + 1);
+    store(buf);
+    __syncthreads();
+    if (it + 1 < it1) {
+      if (++kc == kch) {
+        kc = 0;
+        setup_tap(++tp);
+      }
+      load(kc * BK);
+    }
     const float* Ab = As + buf * A_TILE + (wm * TM * 32 + l31) * PITCH + h * 4;
     const float* Bb = BKM ? Bs + buf * B_TILE + (h * 4) * BN + wn * TN * 32 + l31
                           : Bs + buf * B_TILE + (wn * TN * 32 + l31) * PITCH + h * 4;
@@ -210,9 +247,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
-    if (more) store(buf ^ 1);
-    __syncthreads();
   }
+  if (it0 >= it1) __syncthreads();  // s_orow visibility when this block has no K work
 
   // ---- epilogue
   const long long obo = b0 * d.o_bs0 + b1 * d.o_bs1;
@@ -253,6 +289,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const sdm_igemm_de
     const long long orow = e / d.N;
     const int col = (int)(e - orow * d.N);
     float v = d.ws[e] * d.alpha + (d.bias ? d.bias[col] : 0.f);
+    d.ws[e] = 0.f;  // leave the scratch zero-filled for the next split-K launch
     if (d.out_preact) d.out_preact[orow * d.ldo + col] = v;
     v = sdm_act(v, d.act);
     if (d.res) v += d.res[orow * d.ldres + col];
@@ -262,11 +299,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const sdm_igemm_de
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool BKM>
+template <int BM, int BN, int WM, int WN, bool BKM, bool VEC>
 static int launch_igemm(const IgemmLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = (2 * BM * PITCH + 2 * (BKM ? BK * BN : BN * PITCH)) * sizeof(float) + BM * sizeof(long long);
   static bool attr_set = false;
-  auto kern = igemm_kernel<BM, BN, WM, WN, BKM>;
+  auto kern = igemm_kernel<BM, BN, WM, WN, BKM, VEC>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
@@ -276,7 +313,7 @@ static int launch_igemm(const IgemmLaunch& L, int ntm, hipStream_t st) {
   for (int p = 0; p < L.d.nphase; ++p) taps += L.d.ntaps[p];
   sdm_prof_pre(st);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, L);
-  sdm_prof_post(st, BM == 128 ? 0 : (BM == 64 ? 1 : 2), 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
+  sdm_prof_post(st, BM == 128 ? (BN == 128 ? 0 : 5) : (BM == 64 ? 1 : 2), 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
   SDM_CHECK_LAUNCH("igemm");
   return SDM_OK;
 }
@@ -303,22 +340,30 @@ static int igemm_validate(const sdm_igemm_desc* d) {
   return SDM_OK;
 }
 
+struct TileCfg { int bm, bn; };
+static const TileCfg kCfgs[4] = {{128, 128}, {64, 64}, {32, 128}, {128, 64}};
+
 static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* ws_need) {
   const long M = d->M, N = d->N;
   const long ph = (long)d->nphase * d->batch;
-  int c;
-  if (M <= 32) c = 2;
-  else if (cdiv(M, 128) * cdiv(N, 128) * ph >= 200 && M >= 128 && N >= 96) c = 0;
-  else c = 1;
-  const int bm = c == 0 ? 128 : (c == 1 ? 64 : 32), bn = c == 1 ? 64 : 128;
-  const long blocks = (long)cdiv(M, bm) * cdiv(N, bn) * ph;
   int maxtaps = 0;
   for (int p = 0; p < d->nphase; ++p) maxtaps = d->ntaps[p] > maxtaps ? d->ntaps[p] : maxtaps;
   const int T = maxtaps * cdiv(d->K, BK);
+  auto tiles = [&](int c) { return (long)cdiv(M, kCfgs[c].bm) * cdiv(N, kCfgs[c].bn) * ph; };
+  int c;
+  if (M <= 32) {
+    c = 2;
+  } else {
+    // largest tile that still gives every CU >= 2 workgroups (256 CUs); otherwise 64x64 and split K
+    c = 1;
+    if (M >= 128 && N > 64 && tiles(0) >= 512) c = 0;
+    else if (M >= 128 && tiles(3) >= 512) c = 3;
+  }
+  const long blocks = tiles(c);
   int sk = 1;
-  if (d->batch == 1 && blocks < 192 && T >= 8) {
+  if (d->batch == 1 && blocks < 384 && T >= 16) {
     sk = (int)((512 + blocks - 1) / blocks);
-    if (sk > T / 4) sk = T / 4;
+    if (sk > T / 8) sk = T / 8;
     if (sk > 64) sk = 64;
     if (sk < 1) sk = 1;
   }
@@ -336,6 +381,12 @@ extern "C" size_t sdm_igemm_workspace_bytes(const sdm_igemm_desc* d) {
   return need;
 }
 
+template <int BM, int BN, int WM, int WN>
+static int dispatch_igemm(const IgemmLaunch& L, int ntm, bool kmajor, bool vec, hipStream_t st) {
+  if (kmajor) return vec ? launch_igemm<BM, BN, WM, WN, true, true>(L, ntm, st) : launch_igemm<BM, BN, WM, WN, true, false>(L, ntm, st);
+  return vec ? launch_igemm<BM, BN, WM, WN, false, true>(L, ntm, st) : launch_igemm<BM, BN, WM, WN, false, false>(L, ntm, st);
+}
+
 extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
   int rc = igemm_validate(d);
   if (rc != SDM_OK) return rc;
@@ -347,22 +398,18 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
   igemm_plan(d, &cfg, &L.splitk, &need);
   if (L.splitk > 1 && (d->ws == nullptr || d->ws_bytes < need)) L.splitk = 1;  // no scratch: run unsplit
   L.kchunks = cdiv(d->K, BK);
-  L.vecA = aligned16(d->a.p0) && d->a.ld0 % 4 == 0 && d->a_bs0 % 4 == 0 && d->a_bs1 % 4 == 0 &&
-           (d->a.p1 == nullptr || (aligned16(d->a.p1) && d->a.ld1 % 4 == 0));
-  L.vecB = aligned16(d->b) && d->ldb % 4 == 0 && d->b_tap_stride % 4 == 0 && d->b_bs0 % 4 == 0 && d->b_bs1 % 4 == 0;
+  const bool vecA = aligned16(d->a.p0) && d->a.ld0 % 4 == 0 && d->a_bs0 % 4 == 0 && d->a_bs1 % 4 == 0 &&
+                    (d->a.p1 == nullptr || (aligned16(d->a.p1) && d->a.ld1 % 4 == 0));
+  const bool vecB = aligned16(d->b) && d->ldb % 4 == 0 && d->b_tap_stride % 4 == 0 && d->b_bs0 % 4 == 0 && d->b_bs1 % 4 == 0;
+  const bool vec = vecA && vecB && d->K % 4 == 0 && (!d->b_kmajor || d->N % 4 == 0);
   const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
-  if (L.splitk > 1) {
-    if (hipMemsetAsync(d->ws, 0, need, st) != hipSuccess) return sdm_set_error(SDM_ERR_LAUNCH, "igemm: memset failed");
-  }
-  const int bm = cfg == 0 ? 128 : (cfg == 1 ? 64 : 32), bn = cfg == 1 ? 64 : 128;
-  const int ntm = cdiv(d->M, bm);
-  L.ntn = cdiv(d->N, bn);
-  if (cfg == 0)
-    rc = d->b_kmajor ? launch_igemm<128, 128, 2, 2, true>(L, ntm, st) : launch_igemm<128, 128, 2, 2, false>(L, ntm, st);
-  else if (cfg == 1)
-    rc = d->b_kmajor ? launch_igemm<64, 64, 2, 2, true>(L, ntm, st) : launch_igemm<64, 64, 2, 2, false>(L, ntm, st);
-  else
-    rc = d->b_kmajor ? launch_igemm<32, 128, 1, 4, true>(L, ntm, st) : launch_igemm<32, 128, 1, 4, false>(L, ntm, st);
+  const int ntm = cdiv(d->M, kCfgs[cfg].bm);
+  L.ntn = cdiv(d->N, kCfgs[cfg].bn);
+  const bool km = d->b_kmajor != 0;
+  if (cfg == 0) rc = dispatch_igemm<128, 128, 2, 2>(L, ntm, km, vec, st);
+  else if (cfg == 1) rc = dispatch_igemm<64, 64, 2, 2>(L, ntm, km, vec, st);
+  else if (cfg == 2) rc = dispatch_igemm<32, 128, 1, 4>(L, ntm, km, vec, st);
+  else rc = dispatch_igemm<128, 64, 2, 2>(L, ntm, km, vec, st);
   if (rc != SDM_OK) return rc;
   if (L.splitk > 1) {
     const long long total = (long long)out_rows * d->N;
@@ -382,10 +429,10 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
 // --------------------------------------------------------------------------------------------
 struct WgradLaunch {
   sdm_wgrad_desc d;
-  int splitk, vecG, vecX, ntn, atomic_out;
+  int splitk, ntn, atomic_out;
 };
 
-template <int BT, int WM, int WN>
+template <int BT, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
   const sdm_wgrad_desc& d = L.d;
   constexpr int TM = BT / (WM * 32), TN = BT / (WN * 32);
@@ -411,21 +458,35 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
   const int it0 = (int)((long long)T * ks / L.splitk), it1 = (int)((long long)T * (ks + 1) / L.splitk);
   const int gdy = d.g_dy[tp], gdx = d.g_dx[tp], xdy = d.x_dy[tp], xdx = d.x_dx[tp];
   const int cm = m0 + 4 * (tid % CPR), cn = n0 + 4 * (tid % CPR);
+  const bool gch = cm < d.M, xch = cn < d.N;
+  const bool xsrc0 = cn < d.x.csplit;
+  const bool affine = d.x.scale != nullptr;
+
+  // pixel coordinates of this thread's IT rows, advanced by BK pixels per K-step without divisions
+  int pn[IT], py[IT], px[IT];
+  const int adv_x = BK % d.Wk, q32 = BK / d.Wk;
+  const int adv_y = q32 % d.Hk, adv_n = q32 / d.Hk;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const long long p = (long long)it0 * BK + tid / CPR + RPP * i;
+    const int n = (int)(p / HW), rem = (int)(p - (long long)n * HW);
+    pn[i] = n;
+    py[i] = rem / d.Wk;
+    px[i] = rem - py[i] * d.Wk;
+  }
 
   f32x4 ra[IT], rb[IT];
-  auto load = [&](int it) {
+  auto load = [&]() {
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-      const long long p = (long long)it * BK + tid / CPR + RPP * i;
-      if (p < P) {
-        const int n = (int)(p / HW), rem = (int)(p - (long long)n * HW);
-        const int y = rem / d.Wk, x = rem - y * d.Wk;
+      const int n = pn[i], y = py[i], x = px[i];
+      if (n < d.images) {
         {
           const int sy = y * d.g_stride + gdy, sx = x * d.g_stride + gdx;
-          if ((unsigned)sy < (unsigned)d.g.H && (unsigned)sx < (unsigned)d.g.W && cm < d.M) {
+          if (gch && (unsigned)sy < (unsigned)d.g.H && (unsigned)sx < (unsigned)d.g.W) {
             const float* q = g0 + (((long long)n * d.g.H + sy) * d.g.W + sx) * d.g.ld0 + cm;
-            if (L.vecG && cm + 3 < d.M) {
+            if (VEC) {
               va = *(const f32x4*)q;
             } else {
               va.x = q[0];
@@ -437,10 +498,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
         }
         {
           const int sy = y * d.x_stride + xdy, sx = x * d.x_stride + xdx;
-          if ((unsigned)sy < (unsigned)d.x.H && (unsigned)sx < (unsigned)d.x.W && cn < d.N) {
+          if (xch && (unsigned)sy < (unsigned)d.x.H && (unsigned)sx < (unsigned)d.x.W) {
             const long long row = ((long long)n * d.x.H + sy) * d.x.W + sx;
-            const float* q = (cn < d.x.csplit) ? x0 + row * d.x.ld0 + cn : x1 + row * d.x.ld1 + (cn - d.x.csplit);
-            if (L.vecX && cn + 3 < d.N) {
+            const float* q = xsrc0 ? x0 + row * d.x.ld0 + cn : x1 + row * d.x.ld1 + (cn - d.x.csplit);
+            if (VEC) {
               vb = *(const f32x4*)q;
             } else {
               vb.x = q[0];
@@ -448,7 +509,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
               if (cn + 2 < d.N) vb.z = q[2];
               if (cn + 3 < d.N) vb.w = q[3];
             }
-            if (d.x.scale) {
+            if (affine) {
               const long long so = (long long)n * d.x.aff_nstride + cn;
               const f32x4 sc = *(const f32x4*)(d.x.scale + so);
               const f32x4 sh = *(const f32x4*)(d.x.shift + so);
@@ -459,6 +520,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
       }
       ra[i] = va;
       rb[i] = vb;
+      // advance to the next K-step
+      int nx = x + adv_x, ny = y + adv_y, nn = n + adv_n;
+      if (nx >= d.Wk) { nx -= d.Wk; ny += 1; }
+      if (ny >= d.Hk) { ny -= d.Hk; nn += 1; }
+      px[i] = nx; py[i] = ny; pn[i] = nn;
     }
   };
   auto store = [&](int buf) {
@@ -478,15 +544,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (it0 < it1) {
-    load(it0);
-    store(0);
-  }
-  __syncthreads();
+  if (it0 < it1) load();
   for (int it = it0; it < it1; ++it) {
     const int buf = (it - it0) & 1;
-    const bool more = it + 1 < it1;
-    if (more) load(it + 1);
+    store(buf);
+    __syncthreads();
+    if (it + 1 < it1) load();
     const float* Ab = As + buf * TILE + (h * 4) * BT + wm * TM * 32 + l31;
     const float* Bb = Bs + buf * TILE + (h * 4) * BT + wn * TN * 32 + l31;
 #pragma unroll
@@ -507,8 +570,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
-    if (more) store(buf ^ 1);
-    __syncthreads();
   }
 
   float* dw = d.dw + b0 * d.w_bs0 + b1 * d.w_bs1 + (long long)d.tap_w[tp] * d.w_tap_stride;
@@ -538,17 +599,17 @@ __global__ void zero_rows_kernel(float* p, long long rows, int cols, long long l
   }
 }
 
-template <int BT, int WM, int WN>
+template <int BT, int WM, int WN, bool VEC>
 static int launch_wgrad(const WgradLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = 4 * BK * BT * sizeof(float);
   dim3 grid(ntm * L.ntn, L.d.ntaps * L.splitk, L.d.batch);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<BT, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<BT, WM, WN, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   sdm_prof_pre(st);
-  hipLaunchKernelGGL((wgrad_kernel<BT, WM, WN>), grid, dim3(256), lds, st, L);
+  hipLaunchKernelGGL((wgrad_kernel<BT, WM, WN, VEC>), grid, dim3(256), lds, st, L);
   sdm_prof_post(st, BT == 128 ? 3 : 4,
                 2.0 * L.d.M * L.d.N * (double)L.d.images * L.d.Hk * L.d.Wk * L.d.ntaps * L.d.batch);
   SDM_CHECK_LAUNCH("wgrad");
@@ -572,38 +633,44 @@ extern "C" int sdm_wgrad(const sdm_wgrad_desc* d, sdm_stream_t stream) {
   L.d = *d;
   const long P = (long)d->images * d->Hk * d->Wk;
   const int T = cdiv(P, BK);
-  const bool big = d->M >= 128 && d->N >= 128;
+  // 128x128 tiles only when they alone keep the chip busy; otherwise 64x64 tiles (4x the workgroups per split)
+  const bool big = d->M >= 128 && d->N >= 128 && (long)cdiv(d->M, 128) * cdiv(d->N, 128) * d->ntaps * d->batch >= 256;
   const int bt = big ? 128 : 64;
   const int ntm = cdiv(d->M, bt);
   L.ntn = cdiv(d->N, bt);
   const long blocks = (long)ntm * L.ntn * d->ntaps * d->batch;
   int sk = 1;
-  if (blocks < 384 && T >= 8) {
+  if (blocks < 512 && T >= 16) {
     sk = (int)((768 + blocks - 1) / blocks);
-    if (sk > T / 4) sk = T / 4;
+    if (sk > T / 8) sk = T / 8;
     if (sk > 128) sk = 128;
     if (sk < 1) sk = 1;
   }
   L.splitk = sk;
-  L.atomic_out = (sk > 1 || d->accumulate) ? 1 : 0;
-  L.vecG = aligned16(d->g.p0) && d->g.ld0 % 4 == 0 && d->g_bs0 % 4 == 0 && d->g_bs1 % 4 == 0;
-  L.vecX = aligned16(d->x.p0) && d->x.ld0 % 4 == 0 && d->x_bs0 % 4 == 0 && d->x_bs1 % 4 == 0 &&
-           (d->x.p1 == nullptr || (aligned16(d->x.p1) && d->x.ld1 % 4 == 0));
-  if (sk > 1 && !d->accumulate) {
-    for (int b = 0; b < d->batch; ++b) {
-      for (int t = 0; t < d->ntaps; ++t) {
-        float* p = d->dw + (b / d->bdiv) * d->w_bs0 + (b % d->bdiv) * d->w_bs1 + (long long)d->tap_w[t] * d->w_tap_stride;
-        if (d->ldw == d->N) {
-          if (hipMemsetAsync(p, 0, (size_t)d->M * d->N * sizeof(float), st) != hipSuccess)
-            return sdm_set_error(SDM_ERR_LAUNCH, "wgrad: memset failed");
-        } else {
+  L.atomic_out = (sk > 1 || d->accumulate == 1) ? 1 : 0;
+  const bool vecG = aligned16(d->g.p0) && d->g.ld0 % 4 == 0 && d->g_bs0 % 4 == 0 && d->g_bs1 % 4 == 0 && d->M % 4 == 0;
+  const bool vecX = aligned16(d->x.p0) && d->x.ld0 % 4 == 0 && d->x_bs0 % 4 == 0 && d->x_bs1 % 4 == 0 && d->N % 4 == 0 &&
+                    (d->x.p1 == nullptr || (aligned16(d->x.p1) && d->x.ld1 % 4 == 0));
+  const bool vec = vecG && vecX;
+  if (sk > 1 && d->accumulate == 0) {
+    // one memset when the tap slices tile a contiguous block (conv / linear weights), else per slice
+    bool contiguous = d->batch == 1 && d->ldw == d->N && (d->ntaps == 1 || d->w_tap_stride == (int64_t)d->M * d->N);
+    if (contiguous) {
+      int lo = 255, hi = 0;
+      for (int t = 0; t < d->ntaps; ++t) { lo = d->tap_w[t] < lo ? d->tap_w[t] : lo; hi = d->tap_w[t] > hi ? d->tap_w[t] : hi; }
+      contiguous = (hi - lo + 1) == d->ntaps;
+      if (contiguous) SDM_MEMSET0(d->dw + (long long)lo * d->w_tap_stride, (size_t)d->ntaps * d->M * d->N * sizeof(float), st);
+    }
+    if (!contiguous) {
+      for (int b = 0; b < d->batch; ++b)
+        for (int t = 0; t < d->ntaps; ++t) {
+          float* p = d->dw + (b / d->bdiv) * d->w_bs0 + (b % d->bdiv) * d->w_bs1 + (long long)d->tap_w[t] * d->w_tap_stride;
           hipLaunchKernelGGL(zero_rows_kernel, dim3(cdiv((long)d->M * d->N, 1024)), dim3(256), 0, st, p, (long long)d->M,
                              d->N, (long long)d->ldw);
           SDM_CHECK_LAUNCH("zero_rows");
         }
-      }
     }
   }
-  if (big) return launch_wgrad<128, 2, 2>(L, ntm, st);
-  return launch_wgrad<64, 2, 2>(L, ntm, st);
+  if (big) return vec ? launch_wgrad<128, 2, 2, true>(L, ntm, st) : launch_wgrad<128, 2, 2, false>(L, ntm, st);
+  return vec ? launch_wgrad<64, 2, 2, true>(L, ntm, st) : launch_wgrad<64, 2, 2, false>(L, ntm, st);
 }

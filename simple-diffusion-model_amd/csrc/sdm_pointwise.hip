@@ -640,16 +640,19 @@ extern "C" int sdm_linear_multi(const float* x, int64_t ldx, int M, int K, const
 
 // backward of a small-batch linear y = x W^T + b given dy (already multiplied by act'):
 //   dx[m][k] (+)= sum_o dy[m][o] W[o][k] ;  dW[o][k] += sum_m dy[m][o] x[m][k] ; db[o] += sum_m dy[m][o]
+#define LSB_OC 64
 __global__ __launch_bounds__(256) void linear_small_bwd_dx_kernel(const float* __restrict__ dy, long long lddy,
                                                                   const float* __restrict__ w, float* __restrict__ dx,
-                                                                  long long lddx, int M, int K, int O, int accumulate) {
+                                                                  long long lddx, int M, int K, int O) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int m = blockIdx.y;
+  const int o0 = blockIdx.z * LSB_OC;
   if (k >= K) return;
+  int o1 = o0 + LSB_OC;
+  if (o1 > O) o1 = O;
   float a = 0.f;
-  for (int o = 0; o < O; ++o) a = fmaf(dy[(long long)m * lddy + o], w[(long long)o * K + k], a);
-  if (accumulate) dx[(long long)m * lddx + k] += a;
-  else dx[(long long)m * lddx + k] = a;
+  for (int o = o0; o < o1; ++o) a = fmaf(dy[(long long)m * lddy + o], w[(long long)o * K + k], a);
+  atomicAdd(&dx[(long long)m * lddx + k], a);
 }
 
 __global__ __launch_bounds__(256) void linear_small_bwd_dw_kernel(const float* __restrict__ dy, long long lddy,
@@ -674,8 +677,9 @@ extern "C" int sdm_linear_small_bwd(const float* dy, int64_t lddy, const float* 
   SDM_CHECK_ARG(dy && w && M > 0 && K > 0 && O > 0, "linear_small_bwd: bad args");
   hipStream_t st = (hipStream_t)s;
   if (dx) {
-    hipLaunchKernelGGL(linear_small_bwd_dx_kernel, dim3(cdiv(K, 256), M), dim3(256), 0, st, dy, (long long)lddy, w, dx,
-                       (long long)lddx, M, K, O, dx_accumulate);
+    (void)dx_accumulate;  // always accumulates (see header)
+    hipLaunchKernelGGL(linear_small_bwd_dx_kernel, dim3(cdiv(K, 256), M, cdiv(O, LSB_OC)), dim3(256), 0, st, dy,
+                       (long long)lddy, w, dx, (long long)lddx, M, K, O);
     SDM_CHECK_LAUNCH("linear_small_bwd_dx");
   }
   if (dw) {

@@ -82,6 +82,39 @@ class U_Net(nn.Module):
         return [(n, p) for n, p in self.named_parameters()
                 if ".adagn.y_shift." not in n and not (".attn_layers." in n and ".norm." in n)]
 
+    def grad_blocks(self):
+        """Live parameters grouped by the top-level block whose backward completes them, in completion order
+        (the order the flat gradient buffer and the data-parallel buckets follow)."""
+        L = self.num_layers
+        groups = [("out_layers", self.out_layers)]
+        groups += [(f"up_layers.{i}", self.up_layers[i]) for i in range(L - 1, -1, -1)]
+        groups += [("middle_layer", self.middle_layer)]
+        groups += [(f"down_layers.{k}", self.down_layers[k]) for k in range(L - 1, -1, -1)]
+        groups += [("in_layer", self.in_layer)]
+        if self.cond_emb is not None:
+            groups += [("cond_emb", self.cond_emb)]
+        live = {id(p) for _, p in self.live_parameters()}
+        out = []
+        for name, mod in groups:
+            ps = [p for p in mod.parameters() if id(p) in live]
+            if ps:
+                out.append((name, ps))
+        return out
+
+    def alloc_grads(self):
+        """-> (flat zero-filled fp32 buffer, {param: strided view}, {block: (start, end)}) in completion order."""
+        blocks = self.grad_blocks()
+        dev = next(self.parameters()).device
+        flat = torch.zeros(sum(p.numel() for _, ps in blocks for p in ps), dtype=torch.float32, device=dev)
+        grads, ranges, off = {}, {}, 0
+        for name, ps in blocks:
+            start = off
+            for p in ps:
+                grads[p] = flat[off:off + p.numel()].as_strided(p.shape, p.stride())
+                off += p.numel()
+            ranges[name] = (start, off)
+        return flat, grads, ranges
+
     # ------------------------------------------------------------------ forward
     def _check_input(self, x):
         if x.dim() != 4 or x.shape[1] != self.in_channel:
@@ -130,7 +163,7 @@ class U_Net(nn.Module):
 
     # ------------------------------------------------------------------ backward
     def _backward(self, ctx, out, dout, grads):
-        """grads: {parameter: gradient buffer with the parameter's layout}, filled in place."""
+        """grads: {parameter: ZERO-FILLED gradient buffer with the parameter's layout}, accumulated into."""
         L = self.num_layers
         dout = dout.to(torch.float32).contiguous()
         if self.image_recon:
@@ -181,7 +214,7 @@ class U_Net(nn.Module):
         out = self._run(ctx, x, t, cond)
         loss, dout = ops.mse(out, target.contiguous(), want_grad=True)
         if grads is None:
-            grads = {p: param_grad_like(p) for _, p in self.live_parameters()}
+            _, grads, _ = self.alloc_grads()
         self._backward(ctx, out, dout, grads)
         return loss, grads
 
@@ -199,7 +232,7 @@ class _UNetFunction(torch.autograd.Function):
     @staticmethod
     def backward(fctx, dout):
         net = fctx.net
-        grads = {p: param_grad_like(p) for p in fctx.params}
+        _, grads, _ = net.alloc_grads()
         net._backward(fctx.run, fctx.out, dout, grads)
         fctx.run = None
         return (None, None, None, None) + tuple(grads[p] for p in fctx.params)

@@ -56,8 +56,9 @@ def to_nchw(a):
 
 
 def param_grad_like(p):
-    """Gradient buffer with the parameter's own memory layout (tap-major for conv weights)."""
-    return torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device)
+    """ZERO-FILLED gradient buffer with the parameter's own memory layout (tap-major for conv weights).
+    Backward kernels accumulate into gradient buffers (split-K atomics, column sums), so they start from zero."""
+    return torch.zeros(p.numel(), dtype=p.dtype, device=p.device).as_strided(p.shape, p.stride())
 
 
 class Swish(nn.Module):
@@ -157,12 +158,8 @@ class AdaGN(nn.Module):
         """dout: gradient w.r.t. the modulated tensor.  Returns dz of the producing conv."""
         gn = self.group_norm
         gw, gb = grads[gn.weight], grads[gn.bias]
-        gw.zero_()
-        gb.zero_()
         dz, dmod = ops.gn_adagn_bwd(dout, y.t, y.z, y.n, y.h * y.w, gn.weight, gn.bias, mod, mean, rstd, gw, gb, gn.groups)
         dW, db = grads[self.y_scale.weight], grads[self.y_scale.bias]
-        dW.zero_()
-        db.zero_()
         ops.linear_small_bwd(dmod, ctx.emb, self.y_scale.weight, dx=ctx.demb, dx_accumulate=True, dW=dW, db=db)
         return dz
 
@@ -229,13 +226,11 @@ class ConditionalEmbedding(nn.Module):
             for j, i in enumerate((6, 4, 2, 0)):
                 lin = layers[i]
                 gw, gb = grads[lin.weight], grads[lin.bias]
-                gw.zero_()
-                gb.zero_()
                 x_in = xs[3 - j]
                 if i == 0:
                     ops.linear_small_bwd(g, x_in, lin.weight, dx=None, dW=gw, db=gb)
                 else:
-                    dx = torch.empty_like(x_in)
+                    dx = torch.zeros_like(x_in)
                     ops.linear_small_bwd(g, x_in, lin.weight, dx=dx, dW=gw, db=gb)
                     g = ops.silu_bwd(dx, zs[2 - j])
 

@@ -143,7 +143,7 @@ def version():
     return _lib.sdm_version()
 
 
-PROF_CLASSES = ("igemm_128x128", "igemm_64x64", "igemm_32x128", "wgrad_128x128", "wgrad_64x64")
+PROF_CLASSES = ("igemm_128x128", "igemm_64x64", "igemm_32x128", "wgrad_128x128", "wgrad_64x64", "igemm_128x64")
 
 
 def prof_begin(capacity=100000):
@@ -151,8 +151,8 @@ def prof_begin(capacity=100000):
 
 
 def prof_end():
-    ms = (C.c_double * 5)()
-    n = (C.c_longlong * 5)()
-    fl = (C.c_double * 5)()
+    ms = (C.c_double * 6)()
+    n = (C.c_longlong * 6)()
+    fl = (C.c_double * 6)()
     call("sdm_prof_end", ms, n, fl)
-    return {PROF_CLASSES[i]: dict(ms=ms[i], launches=n[i], flops=fl[i]) for i in range(5)}
+    return {PROF_CLASSES[i]: dict(ms=ms[i], launches=n[i], flops=fl[i]) for i in range(6)}

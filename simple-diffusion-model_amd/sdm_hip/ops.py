@@ -81,7 +81,7 @@ class _Workspace:
         if self.buf is None or self.buf.numel() * 4 < nbytes or self.buf.device != device:
             if torch.cuda.is_current_stream_capturing():
                 raise lib.SdmError("split-K workspace must be sized by a warm-up call before graph capture")
-            self.buf = torch.empty((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)
+            self.buf = torch.zeros((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)   # zero-filled contract
         return self.buf
 
 
@@ -199,7 +199,7 @@ def conv_dgrad(g, g_hw, wt, kind, x_hw, n, res=None, res2=None, dact_z=None, dac
     return out
 
 
-def conv_wgrad(g, g_hw, x, kind, dwt, accumulate=False):
+def conv_wgrad(g, g_hw, x, kind, dwt, accumulate=2):
     """dwt[tap][co][ci] (+)= sum_p g[.][co] * x~[.][ci]; g: [n*ho*wo, c_out] rows; x: Act (input of the conv)."""
     T, cout, cin = dwt.shape
     ho, wo = g_hw
@@ -265,7 +265,7 @@ def linear_rows_dgrad(g, W, res=None, out=None):
     return out
 
 
-def linear_rows_wgrad(g, x, dW, accumulate=False):
+def linear_rows_wgrad(g, x, dW, accumulate=2):
     """dW[O, K] (+)= g[rows, O]^T @ x[rows, K]."""
     rows, O = g.shape
     K = x.shape[1]
@@ -327,7 +327,7 @@ def attention_core_bwd(dres, qkv, P, n, S, heads, dk):
     Sp = P.shape[2]
     ld = qkv.stride(0)
     hd = heads * dk
-    dqkv = torch.empty_like(qkv)
+    dqkv = torch.zeros_like(qkv)          # the k / v slots are accumulated into (split-K atomics)
     ldq = dqkv.stride(0)
     st = _stream()
     # dV[j][dd] = sum_i P[i][j] dres[i][dd]
@@ -343,7 +343,7 @@ def attention_core_bwd(dres, qkv, P, n, S, heads, dk):
     w.ntaps = 1
     w.dw, w.ldw = dqkv.data_ptr() + 8 * dk, ldq
     w.w_bs0, w.w_bs1 = S * ldq, 3 * dk
-    w.alpha, w.accumulate = 1.0, 0
+    w.alpha, w.accumulate = 1.0, 2
     lib.call("sdm_wgrad", C.byref(w), st)
     # dP[i][j] = sum_dd dres[i][dd] v[j][dd]
     dP = torch.empty_like(P)
@@ -385,7 +385,7 @@ def attention_core_bwd(dres, qkv, P, n, S, heads, dk):
     w.ntaps = 1
     w.dw, w.ldw = dqkv.data_ptr() + 4 * dk, ldq
     w.w_bs0, w.w_bs1 = S * ldq, 3 * dk
-    w.alpha, w.accumulate = 1.0, 0
+    w.alpha, w.accumulate = 1.0, 2
     lib.call("sdm_wgrad", C.byref(w), st)
     return dqkv
 
@@ -468,7 +468,7 @@ def linear_small_bwd(dy, x, W, dx=None, dx_accumulate=False, dW=None, db=None):
              dx.stride(0) if dx is not None else 0, int(dx_accumulate), _p(dW), _p(db), M, K, O, _stream())
 
 
-def colsum(x, out, accumulate=False):
+def colsum(x, out, accumulate=True):
     lib.call("sdm_colsum", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), int(accumulate), _stream())
 
 

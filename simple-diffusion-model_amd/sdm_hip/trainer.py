@@ -18,25 +18,6 @@ import torch.distributed as dist
 from . import lib, ops
 
 
-def _flat_order(net):
-    """Live parameters grouped by the top-level block whose backward completes them, in completion order."""
-    L = net.num_layers
-    groups = [("out_layers", net.out_layers)]
-    groups += [(f"up_layers.{i}", net.up_layers[i]) for i in range(L - 1, -1, -1)]
-    groups += [("middle_layer", net.middle_layer)]
-    groups += [(f"down_layers.{k}", net.down_layers[k]) for k in range(L - 1, -1, -1)]
-    groups += [("in_layer", net.in_layer)]
-    if net.cond_emb is not None:
-        groups += [("cond_emb", net.cond_emb)]
-    live = {id(p) for _, p in net.live_parameters()}
-    out = []
-    for name, mod in groups:
-        ps = [p for p in mod.parameters() if id(p) in live]
-        if ps:
-            out.append((name, ps))
-    return out
-
-
 class FusedAdam:
     """torch.optim.Adam(lr, betas, eps=1e-8, weight_decay=0) semantics on flat buffers; state_dict() is
     interchangeable with torch.optim.Adam's (state only for live parameters, keyed by their index in
@@ -108,19 +89,13 @@ class DiffusionTrainer:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         dev = next(net.parameters()).device
         self.dev = dev
-        order = _flat_order(net)
-        total = sum(p.numel() for _, ps in order for p in ps)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.grads, self.items, self.block_range = {}, [], {}
-        off = 0
+        order = net.grad_blocks()
+        self.flat, self.grads, ranges = net.alloc_grads()
+        self.items, self.block_range = [], {}
         for name, ps in order:
-            start, j0 = off, len(self.items)
-            for p in ps:
-                g = self.flat[off:off + p.numel()].as_strided(p.shape, p.stride())
-                self.grads[p] = g
-                self.items.append((p, g))
-                off += p.numel()
-            self.block_range[name] = (start, off, j0, len(self.items))
+            j0 = len(self.items)
+            self.items += [(p, self.grads[p]) for p in ps]
+            self.block_range[name] = (ranges[name][0], ranges[name][1], j0, len(self.items))
         self.order = [n for n, _ in order]
         # buckets = runs of consecutive blocks of >= bucket_mb
         self.buckets, cur = [], None
@@ -174,6 +149,7 @@ class DiffusionTrainer:
         abar = self.schedule.alpha_bar_of(t)
         x_t = ops.q_sample(x0.contiguous(), eps, abar)
         self._done = []
+        self.flat.zero_()                               # backward accumulates (split-K atomics, column sums)
         self.net._block_done_hook = self._on_block_done if self.world > 1 else None
         loss, _ = self.net.loss_and_grads(x_t, t, labels, eps, grads=self.grads)
         self.net._block_done_hook = None
