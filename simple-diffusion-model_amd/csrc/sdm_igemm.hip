@@ -22,7 +22,7 @@ struct IgemmLaunch {
 // One K-step = (tap, 32-channel chunk).  Per-tap state (row pointers, validity) is rebuilt only when the tap
 // changes; inside a tap the loads are pointer + running channel offset, so the steady-state loop is
 // [LDS store | barrier | issue next loads | 4 x (fragment reads + MFMAs)].
-template <int BM, int BN, int WM, int WN, bool BKM, bool VEC>
+template <int BM, int BN, int WM, int WN, bool BKM, bool VEC, bool AFF>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
   const sdm_igemm_desc& d = L.d;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -47,7 +47,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
   const float* bw = d.b + b0 * d.b_bs0 + b1 * d.b_bs1;
   const int HtWt = d.Ht * d.Wt;
   const int K = d.K, N = d.N, csplit = d.a.csplit;
-  const bool affine = d.a.scale != nullptr;
   const int cc4 = 4 * (tid & 7);           // channel offset of this thread's 16-byte chunk inside a K-step
   const int arow = tid >> 3;               // tile row (A, and B when K-contiguous) handled in pass 0
 
@@ -120,79 +119,108 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
   };
 
   f32x4 ra[AIT], rb[BIT];
+  f32x4 rsc[AFF ? AIT : 1], rsh[AFF ? AIT : 1];
+  unsigned amask = 0, bmask = 0;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // load() only ISSUES the global loads of a K-step (VEC path: branch-free, an invalid chunk reads an always-mapped
+  // dummy address); the zero-select and the pending affine are applied in store(), one K-step later, so the loads
+  // stay in flight under the MFMAs of the current step.
   auto load = [&](int c0) {
     const int c = c0 + cc4;
+    amask = 0;
+    bmask = 0;
 #pragma unroll
     for (int i = 0; i < AIT; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (aok[i] && c < K) {
+      const bool use = aok[i] && c < K;
+      amask |= use ? (1u << i) : 0u;
+      if (VEC) {
         const float* p = (c < csplit ? pa0[i] : pa1[i]) + c0;
-        if (VEC) {
-          v = *(const f32x4*)p;
-        } else {
+        p = use ? p : d.a.p0;
+        ra[i] = *(const f32x4*)p;
+        if (AFF) {  // host guarantees K % 4 == 0 and aligned tables
+          const long long so = use ? (long long)a_n[i] * d.a.aff_nstride + c : 0;
+          rsc[i] = *(const f32x4*)(d.a.scale + so);
+          rsh[i] = *(const f32x4*)(d.a.shift + so);
+        }
+      } else {
+        f32x4 v = zero4;
+        if (use) {
+          const float* p = (c < csplit ? pa0[i] : pa1[i]) + c0;
           v.x = p[0];
           if (c + 1 < K) v.y = p[1];
           if (c + 2 < K) v.z = p[2];
           if (c + 3 < K) v.w = p[3];
         }
-        if (affine) {  // host guarantees K % 4 == 0 and aligned tables
-          const long long so = (long long)a_n[i] * d.a.aff_nstride + c;
-          const f32x4 sc = *(const f32x4*)(d.a.scale + so);
-          const f32x4 sh = *(const f32x4*)(d.a.shift + so);
-          v = v * sc + sh;
+        ra[i] = v;
+        if (AFF) {
+          const long long so = use ? (long long)a_n[i] * d.a.aff_nstride + c : 0;
+          rsc[i] = *(const f32x4*)(d.a.scale + so);
+          rsh[i] = *(const f32x4*)(d.a.shift + so);
         }
       }
-      ra[i] = v;
     }
     if (!BKM) {
 #pragma unroll
       for (int i = 0; i < BIT; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (bok[i] && c < K) {
-          const float* p = pb[i] + c0;
-          if (VEC) {
-            v = *(const f32x4*)p;
-          } else {
+        const bool use = bok[i] && c < K;
+        bmask |= use ? (1u << i) : 0u;
+        if (VEC) {
+          const float* p = use ? pb[i] + c0 : d.b;
+          rb[i] = *(const f32x4*)p;
+        } else {
+          f32x4 v = zero4;
+          if (use) {
+            const float* p = pb[i] + c0;
             v.x = p[0];
             if (c + 1 < K) v.y = p[1];
             if (c + 2 < K) v.z = p[2];
             if (c + 3 < K) v.w = p[3];
           }
+          rb[i] = v;
         }
-        rb[i] = v;
       }
     } else {
       const long long koff = (long long)c0 * d.ldb;
 #pragma unroll
       for (int i = 0; i < BIT; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int kk = c0 + tid / CPR + RPP * i;
-        if (bok[i] && kk < K) {
-          const float* p = pb[i] + koff;
-          const int n = n0 + 4 * (tid % CPR);
-          if (VEC) {
-            v = *(const f32x4*)p;
-          } else {
+        const bool use = bok[i] && kk < K;
+        bmask |= use ? (1u << i) : 0u;
+        if (VEC) {
+          const float* p = use ? pb[i] + koff : d.b;
+          rb[i] = *(const f32x4*)p;
+        } else {
+          f32x4 v = zero4;
+          if (use) {
+            const float* p = pb[i] + koff;
+            const int n = n0 + 4 * (tid % CPR);
             v.x = p[0];
             if (n + 1 < N) v.y = p[1];
             if (n + 2 < N) v.z = p[2];
             if (n + 3 < N) v.w = p[3];
           }
+          rb[i] = v;
         }
-        rb[i] = v;
       }
     }
   };
 
   auto store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AIT; ++i) *(f32x4*)&As[buf * A_TILE + (arow + 32 * i) * PITCH + cc4] = ra[i];
+    for (int i = 0; i < AIT; ++i) {
+      f32x4 v = ra[i];
+      if (AFF) v = v * rsc[i] + rsh[i];
+      v = (amask >> i) & 1u ? v : zero4;           // out-of-image taps stay exactly zero AFTER the affine
+      *(f32x4*)&As[buf * A_TILE + (arow + 32 * i) * PITCH + cc4] = v;
+    }
     if (!BKM) {
 #pragma unroll
-      for (int i = 0; i < BIT; ++i) *(f32x4*)&Bs[buf * B_TILE + (arow + 32 * i) * PITCH + cc4] = rb[i];
+      for (int i = 0; i < BIT; ++i)
+        *(f32x4*)&Bs[buf * B_TILE + (arow + 32 * i) * PITCH + cc4] = (bmask >> i) & 1u ? rb[i] : zero4;
     } else {
 #pragma unroll
-      for (int i = 0; i < BIT; ++i) *(f32x4*)&Bs[buf * B_TILE + (tid / CPR + RPP * i) * BN + 4 * (tid % CPR)] = rb[i];
+      for (int i = 0; i < BIT; ++i)
+        *(f32x4*)&Bs[buf * B_TILE + (tid / CPR + RPP * i) * BN + 4 * (tid % CPR)] = (bmask >> i) & 1u ? rb[i] : zero4;
     }
   };
 
@@ -299,11 +327,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const sdm_igemm_de
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool BKM, bool VEC>
+template <int BM, int BN, int WM, int WN, bool BKM, bool VEC, bool AFF>
 static int launch_igemm(const IgemmLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = (2 * BM * PITCH + 2 * (BKM ? BK * BN : BN * PITCH)) * sizeof(float) + BM * sizeof(long long);
   static bool attr_set = false;
-  auto kern = igemm_kernel<BM, BN, WM, WN, BKM, VEC>;
+  auto kern = igemm_kernel<BM, BN, WM, WN, BKM, VEC, AFF>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
@@ -343,34 +371,42 @@ static int igemm_validate(const sdm_igemm_desc* d) {
 struct TileCfg { int bm, bn; };
 static const TileCfg kCfgs[4] = {{128, 128}, {64, 64}, {32, 128}, {128, 64}};
 
+// Tile / split-K choice by a small cost model (cycles per CU): a workgroup spends `mfma` matrix-pipe cycles plus
+// `ovh` issue/barrier cycles per K-step; co-resident workgroups share the matrix pipe but hide each other's
+// overhead.  Split-K adds an atomic pass over the output.
 static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* ws_need) {
   const long M = d->M, N = d->N;
   const long ph = (long)d->nphase * d->batch;
   int maxtaps = 0;
   for (int p = 0; p < d->nphase; ++p) maxtaps = d->ntaps[p] > maxtaps ? d->ntaps[p] : maxtaps;
   const int T = maxtaps * cdiv(d->K, BK);
-  auto tiles = [&](int c) { return (long)cdiv(M, kCfgs[c].bm) * cdiv(N, kCfgs[c].bn) * ph; };
-  int c;
-  if (M <= 32) {
-    c = 2;
-  } else {
-    // largest tile that still gives every CU >= 2 workgroups (256 CUs); otherwise 64x64 and split K
-    c = 1;
-    if (M >= 128 && N > 64 && tiles(0) >= 512) c = 0;
-    else if (M >= 128 && tiles(3) >= 512) c = 3;
+  const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
+  static const double kMfma[4] = {4096, 1024, 1024, 2048};
+  static const int kOcc[4] = {2, 4, 3, 2};
+  const double ovh = 900.0;
+  double best = 1e300;
+  int bc = 1, bs = 1;
+  for (int c = 0; c < 4; ++c) {
+    if (c == 2 && M > 32) continue;
+    if (c != 2 && M <= 32) continue;
+    if ((c == 0 || c == 3) && M < 96) continue;
+    if (c == 0 && N <= 64) continue;
+    const long tiles = (long)cdiv(M, kCfgs[c].bm) * cdiv(N, kCfgs[c].bn) * ph;
+    for (int sk = 1; sk <= 64; sk *= 2) {
+      if (sk > 1 && (d->batch != 1 || sk > T / 8)) break;
+      const long nb = tiles * sk;
+      long b = (nb + 255) / 256;
+      if (b > kOcc[c]) b = kOcc[c];
+      const long rounds = (nb + 256 * b - 1) / (256 * b);
+      const double per_step = kMfma[c] * b > kMfma[c] + ovh ? kMfma[c] * b : kMfma[c] + ovh;
+      double t = (double)rounds * ((double)T / sk) * per_step + 3000.0;
+      if (sk > 1) t += 4000.0 + (double)out_rows * N * 4.0 * (sk + 2) / 256.0 / 2.0;  // atomics + finishing pass
+      if (t < best) { best = t; bc = c; bs = sk; }
+    }
   }
-  const long blocks = tiles(c);
-  int sk = 1;
-  if (d->batch == 1 && blocks < 384 && T >= 16) {
-    sk = (int)((512 + blocks - 1) / blocks);
-    if (sk > T / 8) sk = T / 8;
-    if (sk > 64) sk = 64;
-    if (sk < 1) sk = 1;
-  }
-  long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
-  *cfg = c;
-  *splitk = sk;
-  *ws_need = sk > 1 ? (size_t)out_rows * N * sizeof(float) : 0;
+  *cfg = bc;
+  *splitk = bs;
+  *ws_need = bs > 1 ? (size_t)out_rows * N * sizeof(float) : 0;
 }
 
 extern "C" size_t sdm_igemm_workspace_bytes(const sdm_igemm_desc* d) {
@@ -382,9 +418,18 @@ extern "C" size_t sdm_igemm_workspace_bytes(const sdm_igemm_desc* d) {
 }
 
 template <int BM, int BN, int WM, int WN>
-static int dispatch_igemm(const IgemmLaunch& L, int ntm, bool kmajor, bool vec, hipStream_t st) {
-  if (kmajor) return vec ? launch_igemm<BM, BN, WM, WN, true, true>(L, ntm, st) : launch_igemm<BM, BN, WM, WN, true, false>(L, ntm, st);
-  return vec ? launch_igemm<BM, BN, WM, WN, false, true>(L, ntm, st) : launch_igemm<BM, BN, WM, WN, false, false>(L, ntm, st);
+static int dispatch_igemm(const IgemmLaunch& L, int ntm, bool kmajor, bool vec, bool aff, hipStream_t st) {
+  // the affine-on-load variant exists only for K-contiguous weights (forward convs); other combinations never carry it
+  if (aff) {
+    if (kmajor) return sdm_set_error(SDM_ERR_UNSUPPORTED, "igemm: affine-on-load with K-major weights");
+    return vec ? launch_igemm<BM, BN, WM, WN, false, true, true>(L, ntm, st)
+               : launch_igemm<BM, BN, WM, WN, false, false, true>(L, ntm, st);
+  }
+  if (kmajor)
+    return vec ? launch_igemm<BM, BN, WM, WN, true, true, false>(L, ntm, st)
+               : launch_igemm<BM, BN, WM, WN, true, false, false>(L, ntm, st);
+  return vec ? launch_igemm<BM, BN, WM, WN, false, true, false>(L, ntm, st)
+             : launch_igemm<BM, BN, WM, WN, false, false, false>(L, ntm, st);
 }
 
 extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
@@ -406,10 +451,11 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
   const int ntm = cdiv(d->M, kCfgs[cfg].bm);
   L.ntn = cdiv(d->N, kCfgs[cfg].bn);
   const bool km = d->b_kmajor != 0;
-  if (cfg == 0) rc = dispatch_igemm<128, 128, 2, 2>(L, ntm, km, vec, st);
-  else if (cfg == 1) rc = dispatch_igemm<64, 64, 2, 2>(L, ntm, km, vec, st);
-  else if (cfg == 2) rc = dispatch_igemm<32, 128, 1, 4>(L, ntm, km, vec, st);
-  else rc = dispatch_igemm<128, 64, 2, 2>(L, ntm, km, vec, st);
+  const bool aff = d->a.scale != nullptr;
+  if (cfg == 0) rc = dispatch_igemm<128, 128, 2, 2>(L, ntm, km, vec, aff, st);
+  else if (cfg == 1) rc = dispatch_igemm<64, 64, 2, 2>(L, ntm, km, vec, aff, st);
+  else if (cfg == 2) rc = dispatch_igemm<32, 128, 1, 4>(L, ntm, km, vec, aff, st);
+  else rc = dispatch_igemm<128, 64, 2, 2>(L, ntm, km, vec, aff, st);
   if (rc != SDM_OK) return rc;
   if (L.splitk > 1) {
     const long long total = (long long)out_rows * d->N;
@@ -432,7 +478,7 @@ struct WgradLaunch {
   int splitk, ntn, atomic_out;
 };
 
-template <int BT, int WM, int WN, bool VEC>
+template <int BT, int WM, int WN, bool VEC, bool AFF>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
   const sdm_wgrad_desc& d = L.d;
   constexpr int TM = BT / (WM * 32), TN = BT / (WN * 32);
@@ -460,7 +506,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
   const int cm = m0 + 4 * (tid % CPR), cn = n0 + 4 * (tid % CPR);
   const bool gch = cm < d.M, xch = cn < d.N;
   const bool xsrc0 = cn < d.x.csplit;
-  const bool affine = d.x.scale != nullptr;
 
   // pixel coordinates of this thread's IT rows, advanced by BK pixels per K-step without divisions
   int pn[IT], py[IT], px[IT];
@@ -476,50 +521,52 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
   }
 
   f32x4 ra[IT], rb[IT];
+  f32x4 rsc[AFF ? IT : 1], rsh[AFF ? IT : 1];
+  unsigned gmask = 0, xmask = 0;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load = [&]() {
+    gmask = 0;
+    xmask = 0;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
       const int n = pn[i], y = py[i], x = px[i];
-      if (n < d.images) {
-        {
-          const int sy = y * d.g_stride + gdy, sx = x * d.g_stride + gdx;
-          if (gch && (unsigned)sy < (unsigned)d.g.H && (unsigned)sx < (unsigned)d.g.W) {
-            const float* q = g0 + (((long long)n * d.g.H + sy) * d.g.W + sx) * d.g.ld0 + cm;
-            if (VEC) {
-              va = *(const f32x4*)q;
-            } else {
-              va.x = q[0];
-              if (cm + 1 < d.M) va.y = q[1];
-              if (cm + 2 < d.M) va.z = q[2];
-              if (cm + 3 < d.M) va.w = q[3];
-            }
-          }
+      const bool in = n < d.images;
+      const int gy = y * d.g_stride + gdy, gx = x * d.g_stride + gdx;
+      const int xy = y * d.x_stride + xdy, xx = x * d.x_stride + xdx;
+      const bool gu = in && gch && (unsigned)gy < (unsigned)d.g.H && (unsigned)gx < (unsigned)d.g.W;
+      const bool xu = in && xch && (unsigned)xy < (unsigned)d.x.H && (unsigned)xx < (unsigned)d.x.W;
+      gmask |= gu ? (1u << i) : 0u;
+      xmask |= xu ? (1u << i) : 0u;
+      const long long xrow = ((long long)n * d.x.H + xy) * d.x.W + xx;
+      const float* gq = g0 + (((long long)n * d.g.H + gy) * d.g.W + gx) * d.g.ld0 + cm;
+      const float* xq = xsrc0 ? x0 + xrow * d.x.ld0 + cn : x1 + xrow * d.x.ld1 + (cn - d.x.csplit);
+      if (VEC) {
+        gq = gu ? gq : d.g.p0;
+        xq = xu ? xq : d.x.p0;
+        ra[i] = *(const f32x4*)gq;
+        rb[i] = *(const f32x4*)xq;
+      } else {
+        f32x4 va = zero4, vb = zero4;
+        if (gu) {
+          va.x = gq[0];
+          if (cm + 1 < d.M) va.y = gq[1];
+          if (cm + 2 < d.M) va.z = gq[2];
+          if (cm + 3 < d.M) va.w = gq[3];
         }
-        {
-          const int sy = y * d.x_stride + xdy, sx = x * d.x_stride + xdx;
-          if (xch && (unsigned)sy < (unsigned)d.x.H && (unsigned)sx < (unsigned)d.x.W) {
-            const long long row = ((long long)n * d.x.H + sy) * d.x.W + sx;
-            const float* q = xsrc0 ? x0 + row * d.x.ld0 + cn : x1 + row * d.x.ld1 + (cn - d.x.csplit);
-            if (VEC) {
-              vb = *(const f32x4*)q;
-            } else {
-              vb.x = q[0];
-              if (cn + 1 < d.N) vb.y = q[1];
-              if (cn + 2 < d.N) vb.z = q[2];
-              if (cn + 3 < d.N) vb.w = q[3];
-            }
-            if (affine) {
-              const long long so = (long long)n * d.x.aff_nstride + cn;
-              const f32x4 sc = *(const f32x4*)(d.x.scale + so);
-              const f32x4 sh = *(const f32x4*)(d.x.shift + so);
-              vb = vb * sc + sh;
-            }
-          }
+        if (xu) {
+          vb.x = xq[0];
+          if (cn + 1 < d.N) vb.y = xq[1];
+          if (cn + 2 < d.N) vb.z = xq[2];
+          if (cn + 3 < d.N) vb.w = xq[3];
         }
+        ra[i] = va;
+        rb[i] = vb;
       }
-      ra[i] = va;
-      rb[i] = vb;
+      if (AFF) {
+        const long long so = xu ? (long long)n * d.x.aff_nstride + cn : 0;
+        rsc[i] = *(const f32x4*)(d.x.scale + so);
+        rsh[i] = *(const f32x4*)(d.x.shift + so);
+      }
       // advance to the next K-step
       int nx = x + adv_x, ny = y + adv_y, nn = n + adv_n;
       if (nx >= d.Wk) { nx -= d.Wk; ny += 1; }
@@ -531,8 +578,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int o = buf * TILE + (tid / CPR + RPP * i) * BT + 4 * (tid % CPR);
-      *(f32x4*)&As[o] = ra[i];
-      *(f32x4*)&Bs[o] = rb[i];
+      f32x4 vb = rb[i];
+      if (AFF) vb = vb * rsc[i] + rsh[i];
+      *(f32x4*)&As[o] = (gmask >> i) & 1u ? ra[i] : zero4;
+      *(f32x4*)&Bs[o] = (xmask >> i) & 1u ? vb : zero4;
     }
   };
 
@@ -599,17 +648,17 @@ __global__ void zero_rows_kernel(float* p, long long rows, int cols, long long l
   }
 }
 
-template <int BT, int WM, int WN, bool VEC>
+template <int BT, int WM, int WN, bool VEC, bool AFF>
 static int launch_wgrad(const WgradLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = 4 * BK * BT * sizeof(float);
   dim3 grid(ntm * L.ntn, L.d.ntaps * L.splitk, L.d.batch);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<BT, WM, WN, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<BT, WM, WN, VEC, AFF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   sdm_prof_pre(st);
-  hipLaunchKernelGGL((wgrad_kernel<BT, WM, WN, VEC>), grid, dim3(256), lds, st, L);
+  hipLaunchKernelGGL((wgrad_kernel<BT, WM, WN, VEC, AFF>), grid, dim3(256), lds, st, L);
   sdm_prof_post(st, BT == 128 ? 3 : 4,
                 2.0 * L.d.M * L.d.N * (double)L.d.images * L.d.Hk * L.d.Wk * L.d.ntaps * L.d.batch);
   SDM_CHECK_LAUNCH("wgrad");
@@ -671,6 +720,11 @@ extern "C" int sdm_wgrad(const sdm_wgrad_desc* d, sdm_stream_t stream) {
         }
     }
   }
-  if (big) return vec ? launch_wgrad<128, 2, 2, true>(L, ntm, st) : launch_wgrad<128, 2, 2, false>(L, ntm, st);
-  return vec ? launch_wgrad<64, 2, 2, true>(L, ntm, st) : launch_wgrad<64, 2, 2, false>(L, ntm, st);
+  const bool aff = d->x.scale != nullptr;
+  if (big) {
+    if (aff) return vec ? launch_wgrad<128, 2, 2, true, true>(L, ntm, st) : launch_wgrad<128, 2, 2, false, true>(L, ntm, st);
+    return vec ? launch_wgrad<128, 2, 2, true, false>(L, ntm, st) : launch_wgrad<128, 2, 2, false, false>(L, ntm, st);
+  }
+  if (aff) return vec ? launch_wgrad<64, 2, 2, true, true>(L, ntm, st) : launch_wgrad<64, 2, 2, false, true>(L, ntm, st);
+  return vec ? launch_wgrad<64, 2, 2, true, false>(L, ntm, st) : launch_wgrad<64, 2, 2, false, false>(L, ntm, st);
 }

@@ -106,7 +106,7 @@ def test_conv_fwd_dgrad_wgrad(dev, L, kind, n, cin, cout, h, w):
     assert rel(unrows(out.z, n, out.h, out.w), z) < 2e-5
     # backward: dz = dy * silu'(z)
     dz = ops.silu_bwd(rows(dy), out.z)
-    grads = {conv.weight: L.param_grad_like(conv.weight), conv.bias: torch.empty_like(conv.bias)}
+    grads = {conv.weight: L.param_grad_like(conv.weight), conv.bias: torch.zeros_like(conv.bias)}     # accumulated into
     dx = conv.backward(a, (out.h, out.w), dz, grads)
     assert rel(unrows(dx, n, h, w), xw.grad) < 1e-4, rel(unrows(dx, n, h, w), xw.grad)
     assert rel(grads[conv.weight], wref.grad) < 1e-4, rel(grads[conv.weight], wref.grad)
@@ -156,7 +156,7 @@ def test_linear_rows_and_small(dev):
         gy = torch.randn(rows_, O_, generator=g)
         dx = ops.linear_rows_dgrad(gy.cuda(), W.cuda())
         assert rel(dx, gy @ W) < 2e-5
-        dW = torch.empty(O_, K, device="cuda")
+        dW = torch.zeros(O_, K, device="cuda")                 # wgrad accumulates into a zero-filled buffer
         ops.linear_rows_wgrad(gy.cuda(), x.cuda(), dW)
         assert rel(dW, gy.T @ x) < 2e-5, (rows_, K, O_, rel(dW, gy.T @ x))
 
@@ -336,7 +336,7 @@ def test_unet_loss_and_grads_api_matches_autograd(dev, O):
     y = net(x, t, cond)
     torch.nn.functional.mse_loss(y, tgt).backward()
     for k, p in net.live_parameters():
-        lim = 2e-3 if (".conv_block_" in k and k.endswith("conv_layer.0.bias")) else 1e-5
+        lim = 2e-3 if (".conv_block_" in k and k.endswith("conv_layer.0.bias")) else 5e-5     # atomics reorder sums
         assert rel(grads[p], p.grad) < lim, k
 
 
