@@ -159,6 +159,8 @@ typedef struct sdm_wgrad_desc {
   float* dw;
   int64_t ldw, w_tap_stride;
   int64_t w_bs0, w_bs1;
+  float* dbias;   /* optional [M]: += column sums of the gradient rows (bias gradient); needs plain g rows
+                     (g_stride 1, zero tap offsets); NULL to skip */
   float alpha;
   int accumulate; /* 0: dw is overwritten (library zeroes it first if it splits K); 1: added into;
                      2: dw is known to be all zeros already (no memset; result = the contraction) */
@@ -223,6 +225,12 @@ int sdm_linear_small(const float* x, int64_t ldx, const float* w, const float* b
 typedef struct sdm_linear_job { const float* w; const float* b; float* out; int O; int pad; } sdm_linear_job;
 int sdm_linear_multi(const float* x, int64_t ldx, int M, int K, const sdm_linear_job* jobs_dev, int njobs,
                      int maxO, sdm_stream_t s);
+
+/* Data gradient of njobs projections that shared one input (the y_scale GEMVs): dx[m][k] += sum_j sum_o dy_j[m][o] w_j[o][k].
+ * jobs[j] = {w_j, (unused), dy_j (pitch O_j), O_j}; chunk_job/chunk_o0 (DEVICE int arrays, nchunks long) map each
+ * 64-wide output chunk to its job and first output column. */
+int sdm_linear_multi_bwd_dx(const sdm_linear_job* jobs_dev, const int* chunk_job, const int* chunk_o0, int nchunks,
+                            float* dx, int64_t lddx, int M, int K, sdm_stream_t s);
 
 /* backward of a small-batch linear given dy (already multiplied by act'):
  *   dx[m][k] += sum_o dy[m][o] w[o][k] ; dw[o][k] += sum_m dy[m][o] x[m][k] ; db[o] += sum_m dy[m][o]

@@ -534,6 +534,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
   f32x4 ra[IT], rb[IT];
   f32x4 rsc[AFF ? IT : 1], rsh[AFF ? IT : 1];
   unsigned gmask = 0, xmask = 0;
+  const bool do_bias = d.dbias != nullptr && tile_n == 0 && tp == 0;   // block-uniform
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load = [&]() {
     gmask = 0;
@@ -591,7 +593,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
       const int o = buf * TILE + (tid / CPR + RPP * i) * BT + 4 * (tid % CPR);
       f32x4 vb = rb[i];
       if (AFF) vb = vb * rsc[i] + rsh[i];
-      *(f32x4*)&As[o] = (gmask >> i) & 1u ? ra[i] : zero4;
+      const f32x4 va = (gmask >> i) & 1u ? ra[i] : zero4;
+      if (do_bias) bsum += va;
+      *(f32x4*)&As[o] = va;
       *(f32x4*)&Bs[o] = (xmask >> i) & 1u ? vb : zero4;
     }
   };
@@ -629,6 +633,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  if (do_bias) {  // column sums of the gradient tile rows this block walked: fold the RPP row phases through LDS
+    __syncthreads();
+    *(f32x4*)&As[(tid / CPR) * BT + 4 * (tid % CPR)] = bsum;
+    __syncthreads();
+    if (tid < BT && m0 + tid < d.M) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < RPP; ++r) a += As[r * BT + tid];
+      atomicAdd(&d.dbias[m0 + tid], a);
     }
   }
 
@@ -684,6 +700,8 @@ extern "C" int sdm_wgrad(const sdm_wgrad_desc* d, sdm_stream_t stream) {
   SDM_CHECK_ARG(d->batch >= 1 && d->bdiv >= 1, "wgrad: bad batch");
   SDM_CHECK_ARG(d->g.p1 == nullptr && d->g.scale == nullptr, "wgrad: gradient rows cannot be concat/affine");
   SDM_CHECK_ARG(d->x.p1 != nullptr || d->x.csplit >= d->N, "wgrad: csplit < N without second source");
+  SDM_CHECK_ARG(d->dbias == nullptr || (d->g_stride == 1 && d->g_dy[0] == 0 && d->g_dx[0] == 0 && d->batch == 1),
+                "wgrad: fused bias gradient needs plain gradient rows");
   SDM_CHECK_ARG(d->x.p1 == nullptr || d->x.csplit % 4 == 0, "wgrad: concat split must be a multiple of 4");
   SDM_CHECK_ARG(d->x.scale == nullptr || (d->N % 4 == 0 && d->x.shift && aligned16(d->x.scale) && aligned16(d->x.shift) &&
                                           d->x.aff_nstride % 4 == 0),

@@ -260,31 +260,54 @@ extern "C" int sdm_head_conv_wgrad(const float* x, const float* g, float* dw, fl
 // GroupNorm statistics folded with the AdaGN modulation -> per-(image,channel) affine
 // one block per (image, group); fp64 accumulation
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_affine_kernel(const float* __restrict__ y, long long ldy, int HW, int C,
-                                                        int groups, float eps, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, const float* __restrict__ mod,
-                                                        int mod_ns, float* __restrict__ scale, float* __restrict__ shift,
-                                                        float* __restrict__ mean_o, float* __restrict__ rstd_o) {
-  __shared__ double red[2][4];
+__global__ __launch_bounds__(1024) void gn_affine_kernel(const float* __restrict__ y, long long ldy, int HW, int C,
+                                                         int groups, float eps, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ mod,
+                                                         int mod_ns, float* __restrict__ scale, float* __restrict__ shift,
+                                                         float* __restrict__ mean_o, float* __restrict__ rstd_o, int vec) {
+  __shared__ double red[2][16];
   const int n = blockIdx.x / groups, g = blockIdx.x % groups;
   const int cpg = C / groups;
   const float* base = y + (long long)n * HW * ldy + g * cpg;
   double s1 = 0.0, s2 = 0.0;
   const long long total = (long long)HW * cpg;
-  for (long long e = threadIdx.x; e < total; e += 256) {
-    const long long pix = e / cpg;
-    const int c = (int)(e - pix * cpg);
-    const double v = base[pix * ldy + c];
-    s1 += v;
-    s2 += v * v;
+  if (vec) {  // cpg % 4 == 0 and 16-byte aligned rows: float4 loads, fp32 partials folded into fp64 every 8 loads
+    const int q4 = cpg >> 2;
+    const long long tot4 = (long long)HW * q4;
+    for (long long e0 = threadIdx.x; e0 < tot4; e0 += 1024 * 8) {
+      float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long e = e0 + (long long)u * 1024;
+        if (e < tot4) {
+          const long long pix = e / q4;
+          const int c = (int)(e - pix * q4) * 4;
+          const f32x4 v = *(const f32x4*)(base + pix * ldy + c);
+          p1 += (v.x + v.y) + (v.z + v.w);
+          p2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+      }
+      s1 += p1;
+      s2 += p2;
+    }
+  } else {
+    for (long long e = threadIdx.x; e < total; e += 1024) {
+      const long long pix = e / cpg;
+      const int c = (int)(e - pix * cpg);
+      const double v = base[pix * ldy + c];
+      s1 += v;
+      s2 += v * v;
+    }
   }
   s1 = wave_sum_d(s1);
   s2 = wave_sum_d(s2);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
   __syncthreads();
-  s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-  s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  s1 = 0.0;
+  s2 = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { s1 += red[0][w]; s2 += red[1][w]; }
   const double mean = s1 / (double)total;
   double var = s2 / (double)total - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -294,7 +317,7 @@ __global__ __launch_bounds__(256) void gn_affine_kernel(const float* __restrict_
     mean_o[n * groups + g] = mu;
     rstd_o[n * groups + g] = rstd;
   }
-  for (int c = threadIdx.x; c < cpg; c += 256) {
+  for (int c = threadIdx.x; c < cpg; c += 1024) {
     const int ch = g * cpg + c;
     const float ga = gamma[ch], be = beta[ch];
     const float sm = mod ? mod[(long long)n * mod_ns + ch] : 1.f;
@@ -311,8 +334,9 @@ extern "C" int sdm_gn_affine(const float* y, int64_t ldy, int images, int HW, in
   SDM_CHECK_ARG(y && gamma && beta && scale && shift && mean && rstd, "gn_affine: null pointer");
   SDM_CHECK_ARG(images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_affine: C %d not divisible by groups %d", C,
                 groups);
-  hipLaunchKernelGGL(gn_affine_kernel, dim3(images * groups), dim3(256), 0, (hipStream_t)s, y, (long long)ldy, HW, C,
-                     groups, eps, gamma, beta, mod, mod_nstride, scale, shift, mean, rstd);
+  const int vec = ((C / groups) % 4 == 0) && ldy % 4 == 0 && aligned16(y);
+  hipLaunchKernelGGL(gn_affine_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, y, (long long)ldy, HW, C,
+                     groups, eps, gamma, beta, mod, mod_nstride, scale, shift, mean, rstd, vec);
   SDM_CHECK_LAUNCH("gn_affine");
   return SDM_OK;
 }
@@ -669,6 +693,32 @@ __global__ __launch_bounds__(256) void linear_small_bwd_dw_kernel(const float* _
   }
   if (k < K) dw[(long long)o * K + k] += a;
   if (db && k == 0) db[o] += bsum;
+}
+
+__global__ __launch_bounds__(256) void linear_multi_bwd_dx_kernel(const sdm_linear_job* __restrict__ jobs,
+                                                                  const int* __restrict__ chunk_job,
+                                                                  const int* __restrict__ chunk_o0, float* __restrict__ dx,
+                                                                  long long lddx, int K) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int m = blockIdx.y;
+  const sdm_linear_job j = jobs[chunk_job[blockIdx.z]];
+  const int o0 = chunk_o0[blockIdx.z];
+  if (k >= K) return;
+  int o1 = o0 + LSB_OC;
+  if (o1 > j.O) o1 = j.O;
+  const float* dy = j.out + (long long)m * j.O;
+  float a = 0.f;
+  for (int o = o0; o < o1; ++o) a = fmaf(dy[o], j.w[(long long)o * K + k], a);
+  atomicAdd(&dx[(long long)m * lddx + k], a);
+}
+
+extern "C" int sdm_linear_multi_bwd_dx(const sdm_linear_job* jobs_dev, const int* chunk_job, const int* chunk_o0, int nchunks,
+                                       float* dx, int64_t lddx, int M, int K, sdm_stream_t s) {
+  SDM_CHECK_ARG(jobs_dev && chunk_job && chunk_o0 && dx && nchunks > 0 && M > 0 && K > 0, "linear_multi_bwd_dx: bad args");
+  hipLaunchKernelGGL(linear_multi_bwd_dx_kernel, dim3(cdiv(K, 256), M, nchunks), dim3(256), 0, (hipStream_t)s, jobs_dev,
+                     chunk_job, chunk_o0, dx, (long long)lddx, K);
+  SDM_CHECK_LAUNCH("linear_multi_bwd_dx");
+  return SDM_OK;
 }
 
 extern "C" int sdm_linear_small_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* w, float* dx,

@@ -19,7 +19,7 @@ from sdm_hip import ops
 from sdm_hip.ops import ACT_NONE, ACT_SILU, ACT_TANH, Act
 
 from .custom_layers import *  # noqa: F401,F403  (same star-export surface as the reference)
-from .custom_layers import (ConditionalEmbedding, RunCtx, UNet_ConvBlock, UNetBlock, UNetBlockType,
+from .custom_layers import (AdaGN, ConditionalEmbedding, RunCtx, UNet_ConvBlock, UNetBlock, UNetBlockType,
                             param_grad_like)
 
 
@@ -61,6 +61,8 @@ class U_Net(nn.Module):
         if image_recon:
             outs.append(nn.Tanh())
         self.out_layers = nn.Sequential(*outs)
+        self._adagns = [m for m in self.modules() if isinstance(m, AdaGN)]
+        self._bank = ops.LinearBank()
 
     # ------------------------------------------------------------------ checkpoints
     def custom_load_state_dict(self, state_dict):
@@ -134,6 +136,11 @@ class U_Net(nn.Module):
             if ctx.train and emb.shape[0] != x.shape[0]:
                 raise RuntimeError("training needs one timestep per image (t of shape [N])")
             ctx.emb = emb
+            if self._adagns:             # all y_scale projections of the net in one launch
+                views = self._bank.forward([a.y_scale for a in self._adagns], emb)
+                ctx.mods = dict(zip(self._adagns, views))
+                if ctx.train:
+                    ctx.dmods = dict(zip(self._adagns, self._bank.dviews))
         stem = self.in_layer[0].conv_layer.conv
         a = ops.stem_conv(x, stem.taps(), stem.bias, ACT_SILU, save_z=ctx.train)
         if ctx.train:
@@ -203,6 +210,8 @@ class U_Net(nn.Module):
                      grads[stem.bias].data_ptr(), x.shape[0], x.shape[1], x.shape[2], x.shape[3], stem.cout, st)
         hook("in_layer")
         if self.cond_emb is not None:
+            if ctx.dmods is not None:
+                self._bank.backward_dx(ctx.demb)
             self.cond_emb.backward(ctx, ctx.demb, grads)
             hook("cond_emb")
 

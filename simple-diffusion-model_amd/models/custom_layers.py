@@ -44,6 +44,8 @@ class RunCtx:
         self.rec = {}
         self.emb = None
         self.demb = None
+        self.mods = None      # {AdaGN: modulation rows} when the net evaluated all y_scale projections in one launch
+        self.dmods = None     # {AdaGN: gradient rows} consumed by the batched y_scale data gradient
 
 
 def to_rows(x_nchw):
@@ -131,8 +133,7 @@ class TapConv(nn.Module):
         gradients; returns the gradient w.r.t. the input rows -- already multiplied by silu'(x.z) when the
         input is itself an activation output (then it is that producer's dz)."""
         self.taps()
-        ops.conv_wgrad(dz, y_hw, x, self.kind, self.grad_taps(grads[self.weight]))
-        ops.colsum(dz, grads[self.bias])
+        ops.conv_wgrad(dz, y_hw, x, self.kind, self.grad_taps(grads[self.weight]), dbias=grads[self.bias])
         if not need_dx:
             return None
         ncols = x.c1 if x.t2 is not None else 0
@@ -158,9 +159,14 @@ class AdaGN(nn.Module):
         """dout: gradient w.r.t. the modulated tensor.  Returns dz of the producing conv."""
         gn = self.group_norm
         gw, gb = grads[gn.weight], grads[gn.bias]
-        dz, dmod = ops.gn_adagn_bwd(dout, y.t, y.z, y.n, y.h * y.w, gn.weight, gn.bias, mod, mean, rstd, gw, gb, gn.groups)
+        batched = ctx.dmods is not None
+        dz, dmod = ops.gn_adagn_bwd(dout, y.t, y.z, y.n, y.h * y.w, gn.weight, gn.bias, mod, mean, rstd, gw, gb, gn.groups,
+                                    dmod=ctx.dmods[self] if batched else None)
         dW, db = grads[self.y_scale.weight], grads[self.y_scale.bias]
-        ops.linear_small_bwd(dmod, ctx.emb, self.y_scale.weight, dx=ctx.demb, dx_accumulate=True, dW=dW, db=db)
+        # weight/bias gradients now (the block's gradients must be complete when the block ends: DP buckets);
+        # the embedding gradient of ALL projections is one batched launch at the end of the backward
+        ops.linear_small_bwd(dmod, ctx.emb, self.y_scale.weight, dx=None if batched else ctx.demb, dx_accumulate=True,
+                             dW=dW, db=db)
         return dz
 
     def forward(self, x, emb):
@@ -262,12 +268,10 @@ class AttentionBlock(nn.Module):
         """dO: gradient w.r.t. the block output rows; returns the gradient w.r.t. the input rows."""
         x, qkv, P, res = ctx.rec[self]
         S = x.h * x.w
-        ops.linear_rows_wgrad(dO, res, grads[self.output.weight])
-        ops.colsum(dO, grads[self.output.bias])
+        ops.linear_rows_wgrad(dO, res, grads[self.output.weight], dbias=grads[self.output.bias])
         dres = ops.linear_rows_dgrad(dO, self.output.weight)
         dqkv = ops.attention_core_bwd(dres, qkv, P, x.n, S, self.heads, self.d_k)
-        ops.linear_rows_wgrad(dqkv, x.t, grads[self.projection.weight])
-        ops.colsum(dqkv, grads[self.projection.bias])
+        ops.linear_rows_wgrad(dqkv, x.t, grads[self.projection.weight], dbias=grads[self.projection.bias])
         return ops.linear_rows_dgrad(dqkv, self.projection.weight, res=dO)
 
     def forward(self, x, t=None):
@@ -335,7 +339,7 @@ class UNet_ConvBlock(nn.Module):
             if ctx.train:
                 ctx.rec[self] = (x, y, None, None, None)
             return y, None
-        mod = self.adagn.modulation(emb)
+        mod = ctx.mods[self.adagn] if ctx.mods is not None else self.adagn.modulation(emb)
         scale, shift, mean, rstd = self.adagn.fold(y, mod)
         if ctx.train:
             ctx.rec[self] = (x, y, mod, mean, rstd)

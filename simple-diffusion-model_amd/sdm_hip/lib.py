@@ -53,7 +53,7 @@ class WgradDesc(C.Structure):
         ("x_dy", C.c_int8 * MAX_TAPS), ("x_dx", C.c_int8 * MAX_TAPS),
         ("tap_w", C.c_uint8 * MAX_TAPS),
         ("dw", fp), ("ldw", C.c_int64), ("w_tap_stride", C.c_int64), ("w_bs0", C.c_int64), ("w_bs1", C.c_int64),
-        ("alpha", C.c_float), ("accumulate", C.c_int),
+        ("dbias", fp), ("alpha", C.c_float), ("accumulate", C.c_int),
     ]
 
 
@@ -101,6 +101,7 @@ _PROTOS = {
     "sdm_sinusoid": (_i, [fp, fp, _i, _i, fp, fp]),
     "sdm_linear_small": (_i, [fp, _i64, fp, fp, fp, fp, _i64, fp, _i, _i, _i, _i, fp]),
     "sdm_linear_multi": (_i, [fp, _i64, _i, _i, fp, _i, _i, fp]),
+    "sdm_linear_multi_bwd_dx": (_i, [fp, fp, fp, _i, fp, _i64, _i, _i, fp]),
     "sdm_linear_small_bwd": (_i, [fp, _i64, fp, _i64, fp, fp, _i64, _i, fp, fp, _i, _i, _i, fp]),
     "sdm_colsum": (_i, [fp, _i64, _i, _i, fp, _i, fp]),
     "sdm_silu": (_i, [fp, fp, _sz, fp]),

@@ -199,8 +199,9 @@ def conv_dgrad(g, g_hw, wt, kind, x_hw, n, res=None, res2=None, dact_z=None, dac
     return out
 
 
-def conv_wgrad(g, g_hw, x, kind, dwt, accumulate=2):
-    """dwt[tap][co][ci] (+)= sum_p g[.][co] * x~[.][ci]; g: [n*ho*wo, c_out] rows; x: Act (input of the conv)."""
+def conv_wgrad(g, g_hw, x, kind, dwt, accumulate=2, dbias=None):
+    """dwt[tap][co][ci] (+)= sum_p g[.][co] * x~[.][ci]; g: [n*ho*wo, c_out] rows; x: Act (input of the conv).
+    dbias (zero-filled [c_out]) additionally receives the column sums of g (fused for plain-row gradients)."""
     T, cout, cin = dwt.shape
     ho, wo = g_hw
     d = WgradDesc()
@@ -223,7 +224,11 @@ def conv_wgrad(g, g_hw, x, kind, dwt, accumulate=2):
         d.g_dy[i], d.g_dx[i], d.x_dy[i], d.x_dx[i], d.tap_w[i] = gdy, gdx, xdy, xdx, wi
     d.dw, d.ldw, d.w_tap_stride = _p(dwt), cin, cout * cin
     d.alpha, d.accumulate = 1.0, int(accumulate)
+    if dbias is not None and kind != "ct4":
+        d.dbias = _p(dbias)
     lib.call("sdm_wgrad", C.byref(d), _stream())
+    if dbias is not None and kind == "ct4":        # gathered gradient rows: separate column sum
+        colsum(g, dbias)
 
 
 def linear_rows(x, W, b, act=ACT_NONE, res=None, save_z=False, out=None):
@@ -265,8 +270,8 @@ def linear_rows_dgrad(g, W, res=None, out=None):
     return out
 
 
-def linear_rows_wgrad(g, x, dW, accumulate=2):
-    """dW[O, K] (+)= g[rows, O]^T @ x[rows, K]."""
+def linear_rows_wgrad(g, x, dW, accumulate=2, dbias=None):
+    """dW[O, K] (+)= g[rows, O]^T @ x[rows, K]  (+ dbias[O] += column sums of g)."""
     rows, O = g.shape
     K = x.shape[1]
     d = WgradDesc()
@@ -278,6 +283,7 @@ def linear_rows_wgrad(g, x, dW, accumulate=2):
     d.ntaps = 1
     d.dw, d.ldw, d.w_tap_stride = _p(dW), dW.stride(0), 0
     d.alpha, d.accumulate = 1.0, int(accumulate)
+    d.dbias = _p(dbias)
     lib.call("sdm_wgrad", C.byref(d), _stream())
 
 
@@ -431,12 +437,13 @@ def affine_residual(y, scale, shift, x):
     return Act(out, y.n, y.h, y.w)
 
 
-def gn_adagn_bwd(dout, y, z, n, hw, gamma, beta, mod, mean, rstd, dgamma, dbeta, groups=32):
-    """Returns (dz [rows, C], dmod [n, C] or None)."""
+def gn_adagn_bwd(dout, y, z, n, hw, gamma, beta, mod, mean, rstd, dgamma, dbeta, groups=32, dmod=None):
+    """Returns (dz [rows, C], dmod [n, C] or None).  ``dmod`` may be a preallocated contiguous [n, C] view."""
     C_ = y.shape[1]
     dev = y.device
     dz = torch.empty((n * hw, C_), dtype=torch.float32, device=dev)
-    dmod = torch.empty((n, C_), dtype=torch.float32, device=dev) if mod is not None else None
+    if dmod is None and mod is not None:
+        dmod = torch.empty((n, C_), dtype=torch.float32, device=dev)
     ws = torch.empty((n * C_ * 5,), dtype=torch.float32, device=dev)
     mns = 0 if (mod is None or mod.shape[0] == 1) else mod.stride(0)
     lib.call("sdm_gn_adagn_bwd", _p(dout), dout.stride(0), _p(y), y.stride(0), _p(z), z.stride(0) if z is not None else 0,
@@ -518,3 +525,57 @@ def ddpm_update(x, eps, z, coef):
 
 def ddim_update(x, eps, coef, x0_out=None):
     lib.call("sdm_ddim_update", _p(x), _p(eps), _p(coef), _p(x0_out), x.numel(), _stream())
+
+
+class LinearBank:
+    """The y_scale projections of every AdaGN in the net, evaluated in ONE launch (sdm_linear_multi) and
+    differentiated w.r.t. the shared embedding in ONE launch (sdm_linear_multi_bwd_dx).  Holds the device job
+    tables; rebuilt when a parameter pointer or the embedding batch changes."""
+
+    def __init__(self):
+        self.key = None
+
+    def _build(self, linears, M, dev):
+        import ctypes
+        self.sizes = [l.weight.shape[0] for l in linears]
+        total = sum(self.sizes)
+        self.out = torch.empty(M * total, dtype=torch.float32, device=dev)
+        self.dout = torch.zeros(M * total, dtype=torch.float32, device=dev)
+        self.views, self.dviews = [], []
+        jobs = (lib.LinearJob * len(linears))()
+        bjobs = (lib.LinearJob * len(linears))()
+        cj, co, off = [], [], 0
+        for j, l in enumerate(linears):
+            O = self.sizes[j]
+            v = self.out[off:off + M * O].view(M, O)
+            dv = self.dout[off:off + M * O].view(M, O)
+            self.views.append(v)
+            self.dviews.append(dv)
+            jobs[j].w, jobs[j].b, jobs[j].out, jobs[j].O = l.weight.data_ptr(), l.bias.data_ptr(), v.data_ptr(), O
+            bjobs[j].w, bjobs[j].b, bjobs[j].out, bjobs[j].O = l.weight.data_ptr(), 0, dv.data_ptr(), O
+            for o0 in range(0, O, 64):
+                cj.append(j)
+                co.append(o0)
+            off += M * O
+        self.jobs = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+        self.bjobs = torch.frombuffer(bytearray(bytes(bjobs)), dtype=torch.uint8).to(dev)
+        self.chunk_job = torch.tensor(cj, dtype=torch.int32, device=dev)
+        self.chunk_o0 = torch.tensor(co, dtype=torch.int32, device=dev)
+        self.maxO = max(self.sizes)
+
+    def forward(self, linears, emb):
+        M, K = emb.shape
+        key = (M, emb.device, tuple(l.weight.data_ptr() for l in linears), tuple(l.bias.data_ptr() for l in linears))
+        if key != self.key:
+            if torch.cuda.is_current_stream_capturing():
+                raise lib.SdmError("y_scale job tables must be built by a warm-up call before graph capture")
+            self._build(linears, M, emb.device)
+            self.key = key
+        lib.call("sdm_linear_multi", _p(emb), emb.stride(0), M, K, _p(self.jobs), len(linears), self.maxO, _stream())
+        return self.views
+
+    def backward_dx(self, demb):
+        """demb[m][k] += sum over all projections of dmod_j @ W_j (dmod_j were written into self.dviews)."""
+        M, K = demb.shape
+        lib.call("sdm_linear_multi_bwd_dx", _p(self.bjobs), _p(self.chunk_job), _p(self.chunk_o0), self.chunk_job.numel(),
+                 _p(demb), demb.stride(0), M, K, _stream())
