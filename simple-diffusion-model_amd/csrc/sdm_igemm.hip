@@ -234,27 +234,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  int tp = it0 / kch, kc = it0 - tp * kch;
-  if (it0 < it1) {
-    setup_tap(tp);
-    load(kc * BK);
-  }
-  for (int it = it0; it < it1; ++it) {
-    const int buf = (it - it0) & 1;
-    store(buf);
-    __syncthreads();
-    if (it + 1 < it1) {
-      if (++kc == kch) {
-        kc = 0;
-        setup_tap(++tp);
-      }
-      load(kc * BK);
-    }
+  // Software pipeline (one barrier per K-step):
+  //   registers hold tile it+1, LDS[buf] holds tile it.
+  //   first-half MFMAs | store tile it+1 -> LDS[buf^1] | issue loads of tile it+2 | second-half MFMAs | barrier
+  // so the LDS stores and the next global loads sit BETWEEN matrix instructions of the same wave.
+  auto mma_half = [&](int buf, int half) {
     const float* Ab = As + buf * A_TILE + (wm * TM * 32 + l31) * PITCH + h * 4;
     const float* Bb = BKM ? Bs + buf * B_TILE + (h * 4) * BN + wn * TN * 32 + l31
                           : Bs + buf * B_TILE + (wn * TN * 32 + l31) * PITCH + h * 4;
 #pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) {
+    for (int kq = 0; kq < BK / 16; ++kq) {
+      const int kg = half * (BK / 16) + kq;
       f32x4 af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(Ab + i * 32 * PITCH + kg * 8);
@@ -277,8 +267,36 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
+  };
+
+  int tp = it0 / kch, kc = it0 - tp * kch;
+  auto advance_and_load = [&](int next_it) {
+    if (next_it < it1) {
+      if (++kc == kch) {
+        kc = 0;
+        setup_tap(++tp);
+      }
+      load(kc * BK);
+    } else {
+      amask = 0;
+      bmask = 0;
+    }
+  };
+  if (it0 < it1) {
+    setup_tap(tp);
+    load(kc * BK);
+    store(0);
+    advance_and_load(it0 + 1);
   }
-  if (it0 >= it1) __syncthreads();  // s_orow visibility when this block has no K work
+  __syncthreads();
+  for (int it = it0; it < it1; ++it) {
+    const int buf = (it - it0) & 1;
+    mma_half(buf, 0);
+    store(buf ^ 1);
+    advance_and_load(it + 2);
+    mma_half(buf, 1);
+    __syncthreads();
+  }
 
   // ---- epilogue
   const long long obo = b0 * d.o_bs0 + b1 * d.o_bs1;

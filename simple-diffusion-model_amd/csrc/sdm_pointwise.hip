@@ -111,7 +111,7 @@ extern "C" int sdm_stem_conv_wgrad(const float* x, const float* g, float* dw, fl
   const long long P = (long long)images * H * W;
   SDM_MEMSET0(dw, (size_t)9 * Cout * Cin * sizeof(float), st);
   if (db) SDM_MEMSET0(db, (size_t)Cout * sizeof(float), st);
-  int ppb = (int)((P + 511) / 512);
+  int ppb = (int)((P + 95) / 96);          // ~96 workgroups: few adders per gradient word (atomics contend otherwise)
   ppb = ((ppb + STEM_PIX - 1) / STEM_PIX) * STEM_PIX;
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3(cdiv(P, ppb)), dim3(256), 0, st, x, g, dw, db, images, Cin, H, W, Cout, ppb);
   SDM_CHECK_LAUNCH("stem_conv_wgrad");
@@ -249,7 +249,7 @@ extern "C" int sdm_head_conv_wgrad(const float* x, const float* g, float* dw, fl
   const long long P = (long long)images * H * W;
   SDM_MEMSET0(dw, (size_t)9 * Cout * Cin * sizeof(float), st);
   if (db) SDM_MEMSET0(db, (size_t)Cout * sizeof(float), st);
-  int ppb = (int)((P + 1023) / 1024);
+  int ppb = (int)((P + 127) / 128);
   if (ppb < 1) ppb = 1;
   hipLaunchKernelGGL(head_wgrad_kernel, dim3(cdiv(P, ppb)), dim3(256), 0, st, x, g, dw, db, images, Cin, H, W, Cout, ppb);
   SDM_CHECK_LAUNCH("head_conv_wgrad");

@@ -109,8 +109,8 @@ class DiffusionTrainer:
         if seed is not None:
             self.gen.manual_seed(seed)
         if self.world > 1:                            # identical replicas: rank 0's parameters everywhere
-            for p in net.parameters():
-                dist.broadcast(p.data, src=0, group=self.pg)
+            for p in net.parameters():      # dense storage view: conv weights are permuted (non-contiguous) views
+                dist.broadcast(p.data.as_strided((p.numel(),), (1,), p.storage_offset()), src=0, group=self.pg)
 
     # -- pieces -------------------------------------------------------------------------------
     def draw(self, x0):

@@ -1,0 +1,85 @@
+"""Data-parallel training path end to end on ONE GPU: two ranks (gloo backend on CUDA tensors, both on cuda:0)
+each train on half of a batch through DiffusionTrainer (bucketed all-reduce hooked into the backward, per-bucket
+fused Adam with grad_scale = 1/world); the result must equal a single-rank run on the whole batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+NARROW = dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=32, cond_dim=3, num_layers=2,
+              attn_layers=[1], num_heads=2, dim_per_head=16, min_channel=32, max_channel=64)
+
+
+def _setup_paths():
+    for p in (ROOT, os.path.join(ROOT, "simple-diffusion-model_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _data():
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(2, 4, 3, 16, 16, generator=g)
+    eps = torch.randn(2, 4, 3, 16, 16, generator=g)
+    t = torch.randint(1, 1000, (2, 4), generator=g)
+    lab = torch.eye(3)[torch.randint(0, 3, (2, 4), generator=g)]
+    return x0, eps, t, lab
+
+
+def _train(world, rank, pg_ready):
+    _setup_paths()
+    import degraders as D
+    from models.U_Net import U_Net
+    from oracle import unet_oracle as O
+    from sdm_hip.trainer import DiffusionTrainer
+    cfg = O.full_cfg(NARROW)
+    net = U_Net(**cfg)
+    net.load_state_dict(O.seeded_params(cfg, seed=3, gain=1.8), strict=True)
+    net = net.cuda()
+    tr = DiffusionTrainer(net, D.CosineNoiseDegradation(1000), lr=2e-3, bucket_mb=1)
+    assert tr.world == world
+    x0, eps, t, lab = _data()
+    per = 4 // world
+    sl = slice(rank * per, (rank + 1) * per)
+    losses = []
+    for i in range(2):
+        losses.append(float(tr.step(x0[i, sl].cuda(), lab[i, sl].cuda(), eps=eps[i, sl].cuda(), t=t[i, sl].cuda())))
+    torch.cuda.synchronize()
+    return {k: v.detach().cpu().contiguous().clone() for k, v in net.state_dict().items()}, losses, len(tr.reducer.buckets)
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sd, losses, nb = _train(world, rank, True)
+        if rank == 0:
+            torch.save({"sd": sd, "losses": losses, "buckets": nb}, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_equals_single_rank(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    dp = torch.load(out, weights_only=True)
+    assert dp["buckets"] >= 2
+    ref_sd, ref_losses, _ = _train(1, 0, False)
+    bad = []
+    for k, v in ref_sd.items():
+        if not torch.allclose(dp["sd"][k], v, rtol=1e-3, atol=2e-5):
+            bad.append((k, float((dp["sd"][k] - v).abs().max())))
+    assert not bad, bad[:8]
