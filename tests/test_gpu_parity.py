@@ -428,3 +428,42 @@ def test_training_steps_golden(dev, O):
     assert len(sd["state"]) == len(net.live_parameters())
     ref_opt = torch.optim.Adam(net.parameters(), lr=2e-3, betas=(0.5, 0.999))
     ref_opt.load_state_dict(sd)
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own unit test (tests/test_u_net_model.py:7-23) and the other BASELINE shapes
+# ------------------------------------------------------------------------------------------------
+def test_reference_unit_test_default_unet_shape(dev):
+    """Default-constructed U_Net() (610.7 M parameters), x_T [1,3,128,128], t=[1000] -> same shape out."""
+    from models.U_Net import U_Net
+    torch.manual_seed(0)
+    net = U_Net().cuda().eval()
+    assert sum(p.numel() for p in net.parameters()) == 610_699_523
+    x = torch.randn(1, 3, 128, 128, device="cuda")
+    with torch.no_grad():
+        y = net(x, torch.tensor([1000], dtype=torch.long, device="cuda"))
+    assert y.shape == (1, 3, 128, 128) and bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize("name,over,n,res", [
+    ("C3 128x128 label-conditioned", dict(cond_dim=10), 2, 128),
+    ("C5 SR 256x256 6-channel + Tanh", dict(in_channel=6, image_recon=True), 1, 256),
+])
+def test_baseline_shapes_vs_oracle(dev, O, name, over, n, res):
+    """Standard architecture at the other BASELINE.json resolutions (attention S up to 4096) against the oracle."""
+    from models.U_Net import U_Net
+    cfg = dict(O.STANDARD_CFG, **over)
+    torch.manual_seed(1)
+    net = U_Net(**cfg)
+    P = {k: v.detach().clone().contiguous() for k, v in net.state_dict().items()}
+    net = net.cuda().eval()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(n, cfg["in_channel"], res, res, generator=g)
+    t = torch.randint(1, 1000, (n,), generator=g)
+    cond = torch.eye(10)[torch.randint(0, 10, (n,), generator=g)] if cfg["cond_dim"] else None
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = O.unet_forward(P, cfg, x, t, cond)
+        y = net(x.cuda(), t.cuda(), cond.cuda() if cond is not None else None)
+    assert torch.allclose(y.cpu(), ref, rtol=RTOL, atol=ATOL), (name, float((y.cpu() - ref).abs().max()))
+    assert rel(y, ref) < 2e-5, (name, rel(y, ref))
