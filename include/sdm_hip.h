@@ -178,10 +178,13 @@ int sdm_head_conv(const float* x_nhwc, const float* w_tap, const float* bias, fl
 /* data-gradient of the head conv: dy NCHW [images,Cout,H,W] -> dx NHWC [rows][Cin], times silu'(z). */
 int sdm_head_conv_dgrad(const float* dy_nchw, const float* w_tap, float* dx_nhwc, const float* dact_z,
                         int images, int Cin, int H, int W, int Cout, sdm_stream_t s);
-/* weight/bias gradient of stem (x NCHW, g NHWC) and head (x NHWC, g NCHW); dw tap-major. */
-int sdm_stem_conv_wgrad(const float* x_nchw, const float* g_nhwc, float* dw_tap, float* dbias,
+/* weight/bias gradient of stem (x NCHW, g NHWC) and head (x NHWC, g NCHW); dw tap-major.  Both ACCUMULATE into
+ * dw / dbias (hand in zero-filled buffers) and need ws = sdm_edge_wgrad_workspace_bytes(small_channels, C) bytes:
+ * per-workgroup partial slabs folded by a second pass (no atomics on the weight gradient). */
+size_t sdm_edge_wgrad_workspace_bytes(int small_channels, int C);
+int sdm_stem_conv_wgrad(const float* x_nchw, const float* g_nhwc, float* dw_tap, float* dbias, float* ws,
                         int images, int Cin, int H, int W, int Cout, sdm_stream_t s);
-int sdm_head_conv_wgrad(const float* x_nhwc, const float* g_nchw, float* dw_tap, float* dbias,
+int sdm_head_conv_wgrad(const float* x_nhwc, const float* g_nchw, float* dw_tap, float* dbias, float* ws,
                         int images, int Cin, int H, int W, int Cout, sdm_stream_t s);
 
 /* GroupNorm(32) statistics of y [images][HW][C] folded with the AdaGN modulation into the

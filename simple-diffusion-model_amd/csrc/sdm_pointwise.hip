@@ -3,20 +3,30 @@
 #include "sdm_common.h"
 
 // --------------------------------------------------------------------------------------------
-// stem: Conv2d(Cin<=8 -> C) k3 p1, NCHW image in, NHWC rows out (+SiLU)
-// block = 256 threads over output channels; PIX pixels per block share their input patches via LDS
+// Edge convolutions (3 or 6 image channels on one side).  The small channel count is a template parameter so that
+// every per-thread array is indexed by compile-time constants and stays in registers (a runtime-indexed array
+// would live in scratch memory).
 // --------------------------------------------------------------------------------------------
 #define STEM_PIX 32
 #define EDGE_MAXC 8
 
-__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ out,
-                                                        float* __restrict__ preact, int images, int Cin, int H, int W,
-                                                        int Cout, int act) {
-  __shared__ float patch[STEM_PIX][EDGE_MAXC * 9];
-  const long long P = (long long)images * H * W;
-  const long long p0 = (long long)blockIdx.x * STEM_PIX;
-  const int K = Cin * 9;
+#define EDGE_DISPATCH(C, CALL)                                   \
+  switch (C) {                                                   \
+    case 1: { constexpr int EC = 1; CALL; } break;               \
+    case 2: { constexpr int EC = 2; CALL; } break;               \
+    case 3: { constexpr int EC = 3; CALL; } break;               \
+    case 4: { constexpr int EC = 4; CALL; } break;               \
+    case 5: { constexpr int EC = 5; CALL; } break;               \
+    case 6: { constexpr int EC = 6; CALL; } break;               \
+    case 7: { constexpr int EC = 7; CALL; } break;               \
+    default: { constexpr int EC = 8; CALL; } break;              \
+  }
+
+// input patches of STEM_PIX consecutive pixels -> LDS  [pixel][ci*9 + tap]
+template <int CIN>
+__device__ __forceinline__ void stem_fill_patches(float (*patch)[EDGE_MAXC * 9], const float* __restrict__ x, long long p0,
+                                                  long long P, int H, int W) {
+  constexpr int K = CIN * 9;
   for (int e = threadIdx.x; e < STEM_PIX * K; e += 256) {
     const int pi = e / K, k = e - pi * K;
     const int ci = k / 9, tap = k - ci * 9;
@@ -25,20 +35,36 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     if (p < P) {
       const int n = (int)(p / (H * W)), rem = (int)(p - (long long)n * H * W);
       const int y = rem / W + tap / 3 - 1, xx = rem % W + tap % 3 - 1;
-      if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = x[(((long long)n * Cin + ci) * H + y) * W + xx];
+      if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = x[(((long long)n * CIN + ci) * H + y) * W + xx];
     }
     patch[pi][k] = v;
   }
+}
+
+// stem: Conv2d(CIN -> C) k3 p1, NCHW image in, NHWC rows out (+SiLU); threads over output channels
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        float* __restrict__ preact, int images, int H, int W, int Cout,
+                                                        int act) {
+  constexpr int K = CIN * 9;
+  __shared__ float patch[STEM_PIX][EDGE_MAXC * 9];
+  const long long P = (long long)images * H * W;
+  const long long p0 = (long long)blockIdx.x * STEM_PIX;
+  stem_fill_patches<CIN>(patch, x, p0, P, H, W);
   __syncthreads();
   for (int co = threadIdx.x; co < Cout; co += 256) {
-    float wr[EDGE_MAXC * 9];
-    for (int ci = 0; ci < Cin; ++ci)
-      for (int tap = 0; tap < 9; ++tap) wr[ci * 9 + tap] = w[((long long)tap * Cout + co) * Cin + ci];
+    float wr[K];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) wr[ci * 9 + tap] = w[((long long)tap * Cout + co) * CIN + ci];
     const float b = bias ? bias[co] : 0.f;
     for (int pi = 0; pi < STEM_PIX; ++pi) {
       const long long p = p0 + pi;
       if (p >= P) break;
       float a = b;
+#pragma unroll
       for (int k = 0; k < K; ++k) a = fmaf(patch[pi][k], wr[k], a);
       if (preact) preact[p * Cout + co] = a;
       out[p * Cout + co] = sdm_act(a, act);
@@ -51,98 +77,120 @@ extern "C" int sdm_stem_conv(const float* x, const float* w, const float* bias, 
   SDM_CHECK_ARG(x && w && out && images > 0 && H > 0 && W > 0 && Cout > 0, "stem_conv: bad args");
   SDM_CHECK_ARG(Cin >= 1 && Cin <= EDGE_MAXC, "stem_conv: Cin %d not in [1,%d]", Cin, EDGE_MAXC);
   const long long P = (long long)images * H * W;
-  hipLaunchKernelGGL(stem_conv_kernel, dim3(cdiv(P, STEM_PIX)), dim3(256), 0, (hipStream_t)s, x, w, bias, out, preact,
-                     images, Cin, H, W, Cout, act);
+  EDGE_DISPATCH(Cin, hipLaunchKernelGGL(stem_conv_kernel<EC>, dim3(cdiv(P, STEM_PIX)), dim3(256), 0, (hipStream_t)s, x, w,
+                                        bias, out, preact, images, H, W, Cout, act));
   SDM_CHECK_LAUNCH("stem_conv");
   return SDM_OK;
 }
 
 // stem weight/bias gradient: dw[tap][co][ci] = sum_p g[p][co] * x[n][ci][p+d(tap)] ; db[co] = sum_p g[p][co]
+// each workgroup walks pix_per_block pixels; thread = output channel, CIN*9+1 register accumulators; partials are
+// written to a scratch slab [block][K+1][Cout] and folded by stem_wgrad_reduce_kernel (no atomics).
+template <int CIN>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                         float* __restrict__ dw, float* __restrict__ db, int images,
-                                                         int Cin, int H, int W, int Cout, int pix_per_block) {
+                                                         float* __restrict__ slab, int images, int H, int W, int Cout,
+                                                         int pix_per_block) {
+  constexpr int K = CIN * 9;
   __shared__ float patch[STEM_PIX][EDGE_MAXC * 9];
   const long long P = (long long)images * H * W;
-  const int K = Cin * 9;
-  const int co = threadIdx.x;  // Cout <= 256 per pass handled by loop below
-  float acc[EDGE_MAXC * 9];
-  float accb = 0.f;
+  const long long pb = (long long)blockIdx.x * pix_per_block;
   for (int cb = 0; cb < Cout; cb += 256) {
-    for (int k = 0; k < EDGE_MAXC * 9; ++k) acc[k] = 0.f;
-    accb = 0.f;
-    const long long pb = (long long)blockIdx.x * pix_per_block;
+    const int co = cb + threadIdx.x;
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    float accb = 0.f;
     for (int q = 0; q < pix_per_block; q += STEM_PIX) {
       __syncthreads();
-      for (int e = threadIdx.x; e < STEM_PIX * K; e += 256) {
-        const int pi = e / K, k = e - pi * K;
-        const int ci = k / 9, tap = k - ci * 9;
-        const long long p = pb + q + pi;
-        float v = 0.f;
-        if (p < P && q + pi < pix_per_block) {
-          const int n = (int)(p / (H * W)), rem = (int)(p - (long long)n * H * W);
-          const int y = rem / W + tap / 3 - 1, xx = rem % W + tap % 3 - 1;
-          if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = x[(((long long)n * Cin + ci) * H + y) * W + xx];
-        }
-        patch[pi][k] = v;
-      }
+      stem_fill_patches<CIN>(patch, x, pb + q, P, H, W);
       __syncthreads();
-      if (cb + co < Cout) {
+      if (co < Cout) {
         for (int pi = 0; pi < STEM_PIX; ++pi) {
           const long long p = pb + q + pi;
           if (p >= P || q + pi >= pix_per_block) break;
-          const float gv = g[p * Cout + cb + co];
+          const float gv = g[p * Cout + co];
           accb += gv;
+#pragma unroll
           for (int k = 0; k < K; ++k) acc[k] = fmaf(gv, patch[pi][k], acc[k]);
         }
       }
     }
-    if (cb + co < Cout) {
-      for (int ci = 0; ci < Cin; ++ci)
-        for (int tap = 0; tap < 9; ++tap) atomicAdd(&dw[((long long)tap * Cout + cb + co) * Cin + ci], acc[ci * 9 + tap]);
-      if (db) atomicAdd(&db[cb + co], accb);
+    if (co < Cout) {
+      float* sl = slab + (long long)blockIdx.x * (K + 1) * Cout;
+#pragma unroll
+      for (int k = 0; k < K; ++k) sl[(long long)k * Cout + co] = acc[k];
+      sl[(long long)K * Cout + co] = accb;
     }
   }
 }
 
-extern "C" int sdm_stem_conv_wgrad(const float* x, const float* g, float* dw, float* db, int images, int Cin, int H, int W,
-                                   int Cout, sdm_stream_t s) {
-  SDM_CHECK_ARG(x && g && dw && Cin >= 1 && Cin <= EDGE_MAXC, "stem_conv_wgrad: bad args");
+// out layout: dw[tap][co][ci] and db[co] from slab [block][ci*9+tap | K][co]
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, float* __restrict__ db,
+                                         int nblocks, int Cin, int Cout) {
+  const int K = Cin * 9;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= (K + 1) * Cout) return;
+  const int k = e / Cout, co = e - k * Cout;
+  float a = 0.f;
+  for (int b = 0; b < nblocks; ++b) a += slab[((long long)b * (K + 1) + k) * Cout + co];
+  if (k == K) {
+    if (db) db[co] += a;
+  } else {
+    const int ci = k / 9, tap = k - ci * 9;
+    dw[((long long)tap * Cout + co) * Cin + ci] += a;
+  }
+}
+
+#define EDGE_WGRAD_BLOCKS 256
+extern "C" size_t sdm_edge_wgrad_workspace_bytes(int Cin_or_Cout_small, int C) {
+  return (size_t)EDGE_WGRAD_BLOCKS * (9 * Cin_or_Cout_small + 1) * C * sizeof(float);
+}
+
+extern "C" int sdm_stem_conv_wgrad(const float* x, const float* g, float* dw, float* db, float* ws, int images, int Cin,
+                                   int H, int W, int Cout, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && g && dw && ws && Cin >= 1 && Cin <= EDGE_MAXC, "stem_conv_wgrad: bad args");
   hipStream_t st = (hipStream_t)s;
   const long long P = (long long)images * H * W;
-  SDM_MEMSET0(dw, (size_t)9 * Cout * Cin * sizeof(float), st);
-  if (db) SDM_MEMSET0(db, (size_t)Cout * sizeof(float), st);
-  int ppb = (int)((P + 95) / 96);          // ~96 workgroups: few adders per gradient word (atomics contend otherwise)
+  int ppb = (int)((P + EDGE_WGRAD_BLOCKS - 1) / EDGE_WGRAD_BLOCKS);
   ppb = ((ppb + STEM_PIX - 1) / STEM_PIX) * STEM_PIX;
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(cdiv(P, ppb)), dim3(256), 0, st, x, g, dw, db, images, Cin, H, W, Cout, ppb);
+  const int nb = cdiv(P, ppb);
+  EDGE_DISPATCH(Cin, hipLaunchKernelGGL(stem_wgrad_kernel<EC>, dim3(nb), dim3(256), 0, st, x, g, ws, images, H, W, Cout, ppb));
   SDM_CHECK_LAUNCH("stem_conv_wgrad");
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv((long)(9 * Cin + 1) * Cout, 256)), dim3(256), 0, st, ws, dw, db, nb,
+                     Cin, Cout);
+  SDM_CHECK_LAUNCH("stem_wgrad_reduce");
   return SDM_OK;
 }
 
 // --------------------------------------------------------------------------------------------
-// head: Conv2d(C -> Cout<=8) k3 p1, NHWC rows in, NCHW out (+Tanh).  One wave per output pixel.
+// head: Conv2d(C -> COUT<=8) k3 p1, NHWC rows in, NCHW out (+Tanh).  One wave per output pixel.
 // --------------------------------------------------------------------------------------------
+template <int COUT>
 __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                        int images, int Cin, int H, int W, int Cout, int act) {
+                                                        int images, int Cin, int H, int W, int act) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long P = (long long)images * H * W;
   for (long long p = (long long)blockIdx.x * 4 + wave; p < P; p += (long long)gridDim.x * 4) {
     const int n = (int)(p / (H * W)), rem = (int)(p - (long long)n * H * W);
     const int y = rem / W, xx = rem % W;
-    float acc[EDGE_MAXC];
-    for (int co = 0; co < EDGE_MAXC; ++co) acc[co] = 0.f;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
     for (int tap = 0; tap < 9; ++tap) {
       const int sy = y + tap / 3 - 1, sx = xx + tap % 3 - 1;
       if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) continue;
       const float* xr = x + (((long long)n * H + sy) * W + sx) * Cin;
       for (int c = lane; c < Cin; c += 64) {
         const float xv = xr[c];
-        for (int co = 0; co < Cout; ++co) acc[co] = fmaf(xv, w[((long long)tap * Cout + co) * Cin + c], acc[co]);
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xv, w[((long long)tap * COUT + co) * Cin + c], acc[co]);
       }
     }
-    for (int co = 0; co < Cout; ++co) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
       const float v = wave_sum(acc[co]);
-      if (lane == co) out[(((long long)n * Cout + co) * H + y) * W + xx] = sdm_act(v + (bias ? bias[co] : 0.f), act);
+      if (lane == co) out[(((long long)n * COUT + co) * H + y) * W + xx] = sdm_act(v + (bias ? bias[co] : 0.f), act);
     }
   }
 }
@@ -154,16 +202,17 @@ extern "C" int sdm_head_conv(const float* x, const float* w, const float* bias, 
   const long long P = (long long)images * H * W;
   int grid = (int)((P + 3) / 4);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(head_conv_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, x, w, bias, out, images, Cin, H, W, Cout,
-                     act);
+  EDGE_DISPATCH(Cout, hipLaunchKernelGGL(head_conv_kernel<EC>, dim3(grid), dim3(256), 0, (hipStream_t)s, x, w, bias, out,
+                                         images, Cin, H, W, act));
   SDM_CHECK_LAUNCH("head_conv");
   return SDM_OK;
 }
 
 // dx[p][c] = silu'(z[p][c]) * sum_tap sum_co dy[n][co][p - d(tap)] * w[tap][co][c]
+template <int COUT>
 __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                          float* __restrict__ dx, const float* __restrict__ z, int images,
-                                                         int Cin, int H, int W, int Cout) {
+                                                         int Cin, int H, int W) {
   __shared__ float g[4][9 * EDGE_MAXC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long P = (long long)images * H * W;
@@ -173,11 +222,11 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
     if (p < P) {
       const int n = (int)(p / (H * W)), rem = (int)(p - (long long)n * H * W);
       const int y = rem / W, xx = rem % W;
-      for (int e = lane; e < 9 * Cout; e += 64) {
-        const int tap = e / Cout, co = e - tap * Cout;
+      for (int e = lane; e < 9 * COUT; e += 64) {
+        const int tap = e / COUT, co = e - tap * COUT;
         const int sy = y - (tap / 3 - 1), sx = xx - (tap % 3 - 1);
         float v = 0.f;
-        if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) v = dy[(((long long)n * Cout + co) * H + sy) * W + sx];
+        if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) v = dy[(((long long)n * COUT + co) * H + sy) * W + sx];
         g[wave][e] = v;
       }
     }
@@ -185,7 +234,8 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
     if (p < P) {
       for (int c = lane; c < Cin; c += 64) {
         float a = 0.f;
-        for (int e = 0; e < 9 * Cout; ++e) a = fmaf(g[wave][e], w[(long long)e * Cin + c], a);
+#pragma unroll
+        for (int e = 0; e < 9 * COUT; ++e) a = fmaf(g[wave][e], w[(long long)e * Cin + c], a);
         if (z) a *= sdm_dsilu(z[p * Cin + c]);
         dx[p * Cin + c] = a;
       }
@@ -199,60 +249,79 @@ extern "C" int sdm_head_conv_dgrad(const float* dy, const float* w, float* dx, c
   const long long P = (long long)images * H * W;
   int grid = (int)((P + 3) / 4);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(head_dgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, dy, w, dx, z, images, Cin, H, W, Cout);
+  EDGE_DISPATCH(Cout, hipLaunchKernelGGL(head_dgrad_kernel<EC>, dim3(grid), dim3(256), 0, (hipStream_t)s, dy, w, dx, z,
+                                         images, Cin, H, W));
   SDM_CHECK_LAUNCH("head_conv_dgrad");
   return SDM_OK;
 }
 
-// dw[tap][co][c] = sum_p g[n][co][p] * x[p + d(tap)][c]; threads over c, Cout*9 accumulators each
+// dw[tap][co][c] = sum_p g[n][co][p] * x[p + d(tap)][c]; threads over c, COUT*9 register accumulators each,
+// partials to a slab [block][tap*COUT+co | 9*COUT (unused)][Cin]; bias sums by the first COUT threads.
+template <int COUT>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                         float* __restrict__ dw, float* __restrict__ db, int images,
-                                                         int Cin, int H, int W, int Cout, int pix_per_block) {
+                                                         float* __restrict__ slab, float* __restrict__ db, int images,
+                                                         int Cin, int H, int W, int pix_per_block) {
   const long long P = (long long)images * H * W;
   const long long pb = (long long)blockIdx.x * pix_per_block;
   for (int c = threadIdx.x; c < Cin; c += 256) {
-    float acc[9 * EDGE_MAXC];
-    for (int k = 0; k < 9 * EDGE_MAXC; ++k) acc[k] = 0.f;
+    float acc[9 * COUT];
+#pragma unroll
+    for (int k = 0; k < 9 * COUT; ++k) acc[k] = 0.f;
     for (int q = 0; q < pix_per_block; ++q) {
       const long long p = pb + q;
       if (p >= P) break;
       const int n = (int)(p / (H * W)), rem = (int)(p - (long long)n * H * W);
       const int y = rem / W, xx = rem % W;
-      float gv[EDGE_MAXC];
-      for (int co = 0; co < Cout; ++co) gv[co] = g[(((long long)n * Cout + co) * H + y) * W + xx];
+      float gv[COUT];
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) gv[co] = g[(((long long)n * COUT + co) * H + y) * W + xx];
+#pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int sy = y + tap / 3 - 1, sx = xx + tap % 3 - 1;
         if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) continue;
         const float xv = x[(((long long)n * H + sy) * W + sx) * Cin + c];
-        for (int co = 0; co < Cout; ++co) acc[tap * EDGE_MAXC + co] = fmaf(gv[co], xv, acc[tap * EDGE_MAXC + co]);
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[tap * COUT + co] = fmaf(gv[co], xv, acc[tap * COUT + co]);
       }
     }
-    for (int tap = 0; tap < 9; ++tap)
-      for (int co = 0; co < Cout; ++co) atomicAdd(&dw[((long long)tap * Cout + co) * Cin + c], acc[tap * EDGE_MAXC + co]);
+    float* sl = slab + (long long)blockIdx.x * (9 * COUT) * Cin;
+#pragma unroll
+    for (int k = 0; k < 9 * COUT; ++k) sl[(long long)k * Cin + c] = acc[k];
   }
-  if (db && threadIdx.x < Cout) {
+  if (db && threadIdx.x < COUT) {
     float a = 0.f;
     for (int q = 0; q < pix_per_block; ++q) {
       const long long p = pb + q;
       if (p >= P) break;
       const int n = (int)(p / (H * W)), rem = (int)(p - (long long)n * H * W);
-      a += g[((long long)n * Cout + threadIdx.x) * H * W + rem];
+      a += g[((long long)n * COUT + threadIdx.x) * H * W + rem];
     }
     atomicAdd(&db[threadIdx.x], a);
   }
 }
 
-extern "C" int sdm_head_conv_wgrad(const float* x, const float* g, float* dw, float* db, int images, int Cin, int H, int W,
-                                   int Cout, sdm_stream_t s) {
-  SDM_CHECK_ARG(x && g && dw && Cout >= 1 && Cout <= EDGE_MAXC, "head_conv_wgrad: bad args");
+__global__ void head_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nblocks, int Cin,
+                                         int Cout) {
+  const int e = blockIdx.x * 256 + threadIdx.x;      // e = (tap*Cout+co)*Cin + c == index into dw
+  if (e >= 9 * Cout * Cin) return;
+  float a = 0.f;
+  for (int b = 0; b < nblocks; ++b) a += slab[(long long)b * 9 * Cout * Cin + e];
+  dw[e] += a;
+}
+
+extern "C" int sdm_head_conv_wgrad(const float* x, const float* g, float* dw, float* db, float* ws, int images, int Cin,
+                                   int H, int W, int Cout, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && g && dw && ws && Cout >= 1 && Cout <= EDGE_MAXC, "head_conv_wgrad: bad args");
   hipStream_t st = (hipStream_t)s;
   const long long P = (long long)images * H * W;
-  SDM_MEMSET0(dw, (size_t)9 * Cout * Cin * sizeof(float), st);
-  if (db) SDM_MEMSET0(db, (size_t)Cout * sizeof(float), st);
-  int ppb = (int)((P + 127) / 128);
+  int ppb = (int)((P + EDGE_WGRAD_BLOCKS - 1) / EDGE_WGRAD_BLOCKS);
   if (ppb < 1) ppb = 1;
-  hipLaunchKernelGGL(head_wgrad_kernel, dim3(cdiv(P, ppb)), dim3(256), 0, st, x, g, dw, db, images, Cin, H, W, Cout, ppb);
+  const int nb = cdiv(P, ppb);
+  EDGE_DISPATCH(Cout, hipLaunchKernelGGL(head_wgrad_kernel<EC>, dim3(nb), dim3(256), 0, st, x, g, ws, db, images, Cin, H, W,
+                                         ppb));
   SDM_CHECK_LAUNCH("head_conv_wgrad");
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(cdiv((long)9 * Cout * Cin, 256)), dim3(256), 0, st, ws, dw, nb, Cin, Cout);
+  SDM_CHECK_LAUNCH("head_wgrad_reduce");
   return SDM_OK;
 }
 

@@ -168,6 +168,15 @@ class U_Net(nn.Module):
             return _UNetFunction.apply(self, x, t, cond, *[p for _, p in live])
         return self._run(RunCtx(False), x, t, cond)
 
+    def _edge_slab(self, dev):
+        """Scratch for the per-workgroup partial slabs of the stem/head weight gradients (persistent: graph-safe)."""
+        need = max(ops.lib.raw("sdm_edge_wgrad_workspace_bytes")(self.out_channel, self.channel_layers[0]),
+                   ops.lib.raw("sdm_edge_wgrad_workspace_bytes")(self.in_channel, self.channel_layers[0])) // 4
+        slab = getattr(self, "_slab", None)
+        if slab is None or slab.numel() < need or slab.device != dev:
+            self._slab = slab = torch.empty(need, dtype=torch.float32, device=dev)
+        return slab
+
     # ------------------------------------------------------------------ backward
     def _backward(self, ctx, out, dout, grads):
         """grads: {parameter: ZERO-FILLED gradient buffer with the parameter's layout}, accumulated into."""
@@ -181,8 +190,9 @@ class U_Net(nn.Module):
         hin = ctx.rec["head_in"]
         n, H, W = hin.n, hin.h, hin.w
         st = ops._stream()
+        slab = self._edge_slab(dout.device)
         ops.lib.call("sdm_head_conv_wgrad", hin.t.data_ptr(), dout.data_ptr(), head.grad_taps(grads[head.weight]).data_ptr(),
-                     grads[head.bias].data_ptr(), n, hin.c, H, W, self.out_channel, st)
+                     grads[head.bias].data_ptr(), slab.data_ptr(), n, hin.c, H, W, self.out_channel, st)
         dz = torch.empty_like(hin.t)
         ops.lib.call("sdm_head_conv_dgrad", dout.data_ptr(), head.taps().data_ptr(), dz.data_ptr(), hin.z.data_ptr(), n,
                      hin.c, H, W, self.out_channel, st)
@@ -207,7 +217,7 @@ class U_Net(nn.Module):
         stem = self.in_layer[0].conv_layer.conv
         x = ctx.rec["x"]
         ops.lib.call("sdm_stem_conv_wgrad", x.data_ptr(), dz.data_ptr(), stem.grad_taps(grads[stem.weight]).data_ptr(),
-                     grads[stem.bias].data_ptr(), x.shape[0], x.shape[1], x.shape[2], x.shape[3], stem.cout, st)
+                     grads[stem.bias].data_ptr(), slab.data_ptr(), x.shape[0], x.shape[1], x.shape[2], x.shape[3], stem.cout, st)
         hook("in_layer")
         if self.cond_emb is not None:
             if ctx.dmods is not None:

@@ -90,8 +90,9 @@ _PROTOS = {
     "sdm_stem_conv": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
     "sdm_head_conv": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
     "sdm_head_conv_dgrad": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
-    "sdm_stem_conv_wgrad": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
-    "sdm_head_conv_wgrad": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "sdm_edge_wgrad_workspace_bytes": (_sz, [_i, _i]),
+    "sdm_stem_conv_wgrad": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "sdm_head_conv_wgrad": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "sdm_gn_affine": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, fp, fp, fp, fp]),
     "sdm_affine_residual": (_i, [fp, _i64, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, _i, _i, _i, fp]),
     "sdm_gn_adagn_bwd": (_i, [fp, _i64, fp, _i64, fp, _i64, _i, _i, _i, _i, fp, fp, fp, _i, fp, fp, fp, _i64,
