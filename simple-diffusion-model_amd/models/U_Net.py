@@ -197,7 +197,12 @@ class U_Net(nn.Module):
         ops.lib.call("sdm_head_conv_dgrad", dout.data_ptr(), head.taps().data_ptr(), dz.data_ptr(), hin.z.data_ptr(), n,
                      hin.c, H, W, self.out_channel, st)
         dz = self.out_layers[0].backward(ctx, dz, grads)                 # -> dz of the last up-sampler
-        hook = getattr(self, "_block_done_hook", None) or (lambda name: None)
+        user_hook = getattr(self, "_block_done_hook", None)
+
+        def hook(name):            # a block is done when its weight gradients (side stream) have landed too
+            if user_hook is not None:
+                ops.SIDE.join()
+                user_hook(name)
         hook("out_layers")
         pending = {}
         for idx in range(L - 1, -1, -1):                                   # up_layers[idx] handles level k = L-1-idx
@@ -224,6 +229,7 @@ class U_Net(nn.Module):
                 self._bank.backward_dx(ctx.demb)
             self.cond_emb.backward(ctx, ctx.demb, grads)
             hook("cond_emb")
+        ops.SIDE.join()
 
     def loss_and_grads(self, x, t, cond, target, grads=None):
         """One training forward+backward of mean-squared error against ``target`` without going through autograd:

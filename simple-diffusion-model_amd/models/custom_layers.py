@@ -133,7 +133,11 @@ class TapConv(nn.Module):
         gradients; returns the gradient w.r.t. the input rows -- already multiplied by silu'(x.z) when the
         input is itself an activation output (then it is that producer's dz)."""
         self.taps()
-        ops.conv_wgrad(dz, y_hw, x, self.kind, self.grad_taps(grads[self.weight]), dbias=grads[self.bias])
+        if ops.SIDE.enabled:            # weight gradient on the side stream, concurrent with the data gradient below
+            with ops.SIDE.fork(dz, x.t, x.t2, x.scale, x.shift):
+                ops.conv_wgrad(dz, y_hw, x, self.kind, self.grad_taps(grads[self.weight]), dbias=grads[self.bias])
+        else:
+            ops.conv_wgrad(dz, y_hw, x, self.kind, self.grad_taps(grads[self.weight]), dbias=grads[self.bias])
         if not need_dx:
             return None
         ncols = x.c1 if x.t2 is not None else 0
@@ -268,10 +272,18 @@ class AttentionBlock(nn.Module):
         """dO: gradient w.r.t. the block output rows; returns the gradient w.r.t. the input rows."""
         x, qkv, P, res = ctx.rec[self]
         S = x.h * x.w
-        ops.linear_rows_wgrad(dO, res, grads[self.output.weight], dbias=grads[self.output.bias])
+        if ops.SIDE.enabled:
+            with ops.SIDE.fork(dO, res):
+                ops.linear_rows_wgrad(dO, res, grads[self.output.weight], dbias=grads[self.output.bias])
+        else:
+            ops.linear_rows_wgrad(dO, res, grads[self.output.weight], dbias=grads[self.output.bias])
         dres = ops.linear_rows_dgrad(dO, self.output.weight)
         dqkv = ops.attention_core_bwd(dres, qkv, P, x.n, S, self.heads, self.d_k)
-        ops.linear_rows_wgrad(dqkv, x.t, grads[self.projection.weight], dbias=grads[self.projection.bias])
+        if ops.SIDE.enabled:
+            with ops.SIDE.fork(dqkv, x.t):
+                ops.linear_rows_wgrad(dqkv, x.t, grads[self.projection.weight], dbias=grads[self.projection.bias])
+        else:
+            ops.linear_rows_wgrad(dqkv, x.t, grads[self.projection.weight], dbias=grads[self.projection.bias])
         return ops.linear_rows_dgrad(dqkv, self.projection.weight, res=dO)
 
     def forward(self, x, t=None):

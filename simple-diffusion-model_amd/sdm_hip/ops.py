@@ -71,6 +71,45 @@ def plain_rows(r, t, rows=None):
     r.W = 1
 
 
+class _SideStream:
+    """Second HIP stream for weight-gradient kernels.  A conv's weight gradient and data gradient are independent,
+    and at small batch neither fills 256 CUs on its own, so they run concurrently: fork() makes the side stream
+    wait for everything enqueued so far on the current stream, join() makes the current stream wait for the side
+    stream.  Tensors handed to fork() are registered with the caching allocator (record_stream) so their memory is
+    not reused while the side stream still reads them.  SDM_WGRAD_STREAM=0 disables it."""
+
+    def __init__(self):
+        import os
+        self.enabled = os.environ.get("SDM_WGRAD_STREAM", "1") != "0"
+        self.streams = {}
+        self.dirty = False
+
+    def stream(self, device):
+        st = self.streams.get(device)
+        if st is None:
+            st = self.streams[device] = torch.cuda.Stream(device=device)
+        return st
+
+    def fork(self, *tensors):
+        dev = tensors[0].device
+        side = self.stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        for t in tensors:
+            if t is not None:
+                t.record_stream(side)
+        self.dirty = True
+        return torch.cuda.stream(side)
+
+    def join(self):
+        if self.dirty:
+            for dev, side in self.streams.items():
+                torch.cuda.current_stream(dev).wait_stream(side)
+            self.dirty = False
+
+
+SIDE = _SideStream()
+
+
 class _Workspace:
     def __init__(self):
         self.buf = None

@@ -23,6 +23,8 @@ def T(a):
 
 
 def rel(a, b):
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()        # weight gradients may still be in flight on the side stream
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
 
