@@ -105,6 +105,7 @@ class DiffusionTrainer:
         for (s, e, first, last) in self.reducer.buckets:
             self.bucket_jobs.append((self.block_range[first][2], self.block_range[last][3]))
         self.opt = FusedAdam(net, self.items, lr, betas)
+        self.opt_stream = torch.cuda.Stream(device=dev)
         self.gen = torch.Generator(device=dev)
         if seed is not None:
             self.gen.manual_seed(seed)
@@ -119,6 +120,22 @@ class DiffusionTrainer:
         t = torch.randint(self.min_t, self.max_t, (n,), device=self.dev, generator=self.gen)
         return eps, t
 
+    def _bucket_closed(self, name):
+        """Backward hook: a top-level block's gradients are complete.  If that closes a bucket, start its
+        all-reduce (DP) and queue its fused Adam on the optimizer stream, so both overlap the rest of backward."""
+        i = self.reducer.closing.get(name)
+        if i is None:
+            return
+        self.reducer.block_done(name)                                   # async all-reduce when world > 1
+        _, work = self.reducer.pending[-1]
+        cur = torch.cuda.current_stream(self.dev)
+        self.opt_stream.wait_stream(cur)
+        with torch.cuda.stream(self.opt_stream):
+            if work is not None:
+                work.wait()                                             # blocks the optimizer stream only
+            j0, j1 = self.bucket_jobs[i]
+            self.opt.step(j0, j1 - j0, grad_scale=1.0 / self.world, advance=False)
+
     def step(self, x0, labels=None, eps=None, t=None):
         """One optimiser step on the local mini-batch; returns the loss tensor ([1], device)."""
         if eps is None or t is None:
@@ -127,14 +144,12 @@ class DiffusionTrainer:
         x_t = ops.q_sample(x0.contiguous(), eps, abar)
         self.flat.zero_()                               # backward accumulates (split-K atomics, column sums)
         self.reducer.begin_step()
-        self.net._block_done_hook = self.reducer.block_done if self.world > 1 else None
-        loss, _ = self.net.loss_and_grads(x_t, t, labels, eps, grads=self.grads)
-        self.net._block_done_hook = None
-        if self.world > 1:
-            self.opt.step_count += 1
-            for i, _, _ in self.reducer.drain():        # Adam per bucket as its all-reduce lands
-                j0, j1 = self.bucket_jobs[i]
-                self.opt.step(j0, j1 - j0, grad_scale=1.0 / self.world, advance=False)
-        else:
-            self.opt.step()
+        self.opt.step_count += 1
+        self.net._block_done_hook = self._bucket_closed
+        try:
+            loss, _ = self.net.loss_and_grads(x_t, t, labels, eps, grads=self.grads)
+        finally:
+            self.net._block_done_hook = None
+        self.reducer.pending = []
+        torch.cuda.current_stream(self.dev).wait_stream(self.opt_stream)   # next forward sees the updated weights
         return loss
