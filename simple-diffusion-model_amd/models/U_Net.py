@@ -199,9 +199,8 @@ class U_Net(nn.Module):
         dz = self.out_layers[0].backward(ctx, dz, grads)                 # -> dz of the last up-sampler
         user_hook = getattr(self, "_block_done_hook", None)
 
-        def hook(name):            # a block is done when its weight gradients (side stream) have landed too
-            if user_hook is not None:
-                ops.SIDE.join()
+        def hook(name):            # every gradient of the block is enqueued (weight gradients on ops.SIDE's stream:
+            if user_hook is not None:   # a consumer must wait for BOTH streams, see DiffusionTrainer._bucket_closed)
                 user_hook(name)
         hook("out_layers")
         pending = {}

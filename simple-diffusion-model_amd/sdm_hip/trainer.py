@@ -121,16 +121,19 @@ class DiffusionTrainer:
         return eps, t
 
     def _bucket_closed(self, name):
-        """Backward hook: a top-level block's gradients are complete.  If that closes a bucket, start its
-        all-reduce (DP) and queue its fused Adam on the optimizer stream, so both overlap the rest of backward."""
+        """Backward hook: a top-level block's gradients have all been ENQUEUED (data gradients on the compute
+        stream, weight gradients on the side stream).  If that closes a bucket, the optimizer stream waits for
+        both streams, runs the bucket's all-reduce (DP) and then its fused Adam -- the compute stream never waits,
+        so exchange and update overlap the rest of the backward."""
         i = self.reducer.closing.get(name)
         if i is None:
             return
-        self.reducer.block_done(name)                                   # async all-reduce when world > 1
-        _, work = self.reducer.pending[-1]
-        cur = torch.cuda.current_stream(self.dev)
-        self.opt_stream.wait_stream(cur)
+        self.opt_stream.wait_stream(torch.cuda.current_stream(self.dev))
+        if ops.SIDE.enabled:
+            self.opt_stream.wait_stream(ops.SIDE.stream(self.dev))
         with torch.cuda.stream(self.opt_stream):
+            self.reducer.block_done(name)                               # async all-reduce when world > 1
+            _, work = self.reducer.pending[-1]
             if work is not None:
                 work.wait()                                             # blocks the optimizer stream only
             j0, j1 = self.bucket_jobs[i]
