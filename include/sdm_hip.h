@@ -277,7 +277,9 @@ int sdm_step_advance(int* cursor, const int64_t* t_table, const float* coef_tabl
 /* Fused multi-tensor Adam (torch.optim.Adam defaults, train_diffusion.py:214-217): jobs is a DEVICE array. */
 typedef struct sdm_adam_job { float* p; const float* g; float* m; float* v; int64_t n; } sdm_adam_job;
 int sdm_adam_multi(const sdm_adam_job* jobs_dev, int njobs, int64_t max_n, float lr, float beta1, float beta2,
-                   float eps, float bias_c1, float bias_c2, float grad_scale, sdm_stream_t s);
+                   float eps, float bias_c1, float bias_c2, float grad_scale, const float* hyper_dev, sdm_stream_t s);
+/* hyper_dev (optional, DEVICE, 2 floats {lr, step}): when given, lr and the bias corrections 1-beta^step are read /
+ * computed on the device, so a captured hipGraph of the training step can be replayed while lr and the step advance. */
 
 #ifdef __cplusplus
 }

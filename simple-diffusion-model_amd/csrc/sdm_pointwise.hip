@@ -977,8 +977,15 @@ extern "C" int sdm_step_advance(int* cursor, const int64_t* t_table, const float
 // fused multi-tensor Adam (no weight decay, bias-corrected; torch.optim.Adam semantics)
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_multi_kernel(const sdm_adam_job* __restrict__ jobs, float lr, float b1,
-                                                         float b2, float eps, float bc1, float bc2, float gscale) {
+                                                         float b2, float eps, float bc1, float bc2, float gscale,
+                                                         const float* __restrict__ hyper) {
   const sdm_adam_job j = jobs[blockIdx.y];
+  if (hyper) {
+    lr = hyper[0];
+    const float t = hyper[1];
+    bc1 = 1.0f - powf(b1, t);
+    bc2 = 1.0f - powf(b2, t);
+  }
   const float step = lr / bc1;
   const float rs = 1.0f / sqrtf(bc2);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < j.n; i += (long long)gridDim.x * 256) {
@@ -991,12 +998,13 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const sdm_adam_job* __r
   }
 }
 extern "C" int sdm_adam_multi(const sdm_adam_job* jobs_dev, int njobs, int64_t max_n, float lr, float beta1, float beta2,
-                              float eps, float bias_c1, float bias_c2, float grad_scale, sdm_stream_t s) {
+                              float eps, float bias_c1, float bias_c2, float grad_scale, const float* hyper_dev,
+                              sdm_stream_t s) {
   SDM_CHECK_ARG(jobs_dev && njobs > 0 && max_n > 0, "adam_multi: bad args");
   long long g = (max_n + 255) / 256;
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(adam_multi_kernel, dim3((int)g, njobs), dim3(256), 0, (hipStream_t)s, jobs_dev, lr, beta1, beta2, eps,
-                     bias_c1, bias_c2, grad_scale);
+                     bias_c1, bias_c2, grad_scale, hyper_dev);
   SDM_CHECK_LAUNCH("adam_multi");
   return SDM_OK;
 }

@@ -114,7 +114,7 @@ _PROTOS = {
     "sdm_ddpm_update": (_i, [fp, fp, fp, fp, _sz, fp]),
     "sdm_ddim_update": (_i, [fp, fp, fp, fp, _sz, fp]),
     "sdm_step_advance": (_i, [fp, fp, fp, _i, _i, fp, fp, fp]),
-    "sdm_adam_multi": (_i, [fp, _i, _i64, _f, _f, _f, _f, _f, _f, _f, fp]),
+    "sdm_adam_multi": (_i, [fp, _i, _i64, _f, _f, _f, _f, _f, _f, _f, fp, fp]),
 }
 EXPORTS = tuple(_PROTOS)
 

@@ -82,6 +82,7 @@ class _SideStream:
         import os
         self.enabled = os.environ.get("SDM_WGRAD_STREAM", "1") != "0"
         self.streams = {}
+        self.keep = []
         self.dirty = False
 
     def stream(self, device):
@@ -91,12 +92,12 @@ class _SideStream:
         return st
 
     def fork(self, *tensors):
+        """Tensors read on the side stream are kept referenced until join(): their memory cannot be handed out again
+        (on the compute stream) before the side stream is done with them -- also valid under hipGraph capture."""
         dev = tensors[0].device
         side = self.stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        for t in tensors:
-            if t is not None:
-                t.record_stream(side)
+        self.keep.extend(t for t in tensors if t is not None)
         self.dirty = True
         return torch.cuda.stream(side)
 
@@ -105,6 +106,7 @@ class _SideStream:
             for dev, side in self.streams.items():
                 torch.cuda.current_stream(dev).wait_stream(side)
             self.dirty = False
+        self.keep.clear()
 
 
 SIDE = _SideStream()
