@@ -113,8 +113,12 @@ SIDE = _SideStream()
 
 
 class _Workspace:
+    """Zero-filled split-K scratch, grown on demand.  Outgrown buffers are kept referenced: a captured hipGraph may
+    still hold their address."""
+
     def __init__(self):
         self.buf = None
+        self.retired = []
 
     def get(self, nbytes, device):
         if nbytes == 0:
@@ -122,6 +126,8 @@ class _Workspace:
         if self.buf is None or self.buf.numel() * 4 < nbytes or self.buf.device != device:
             if torch.cuda.is_current_stream_capturing():
                 raise lib.SdmError("split-K workspace must be sized by a warm-up call before graph capture")
+            if self.buf is not None:
+                self.retired.append(self.buf)
             self.buf = torch.zeros((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)   # zero-filled contract
         return self.buf
 
@@ -575,6 +581,7 @@ class LinearBank:
 
     def __init__(self):
         self.key = None
+        self.built = {}            # key -> table set; never replaced (captured graphs hold their addresses)
 
     def _build(self, linears, M, dev):
         import ctypes
@@ -608,9 +615,15 @@ class LinearBank:
         M, K = emb.shape
         key = (M, emb.device, tuple(l.weight.data_ptr() for l in linears), tuple(l.bias.data_ptr() for l in linears))
         if key != self.key:
-            if torch.cuda.is_current_stream_capturing():
-                raise lib.SdmError("y_scale job tables must be built by a warm-up call before graph capture")
-            self._build(linears, M, emb.device)
+            if key not in self.built:
+                if torch.cuda.is_current_stream_capturing():
+                    raise lib.SdmError("y_scale job tables must be built by a warm-up call before graph capture")
+                self._build(linears, M, emb.device)
+                self.built[key] = {k: getattr(self, k) for k in ("sizes", "out", "dout", "views", "dviews", "jobs", "bjobs",
+                                                                 "chunk_job", "chunk_o0", "maxO")}
+            else:
+                for k, v in self.built[key].items():
+                    setattr(self, k, v)
             self.key = key
         lib.call("sdm_linear_multi", _p(emb), emb.stride(0), M, K, _p(self.jobs), len(linears), self.maxO, _stream())
         return self.views

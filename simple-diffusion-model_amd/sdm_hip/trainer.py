@@ -109,11 +109,12 @@ class DiffusionTrainer:
             self.bucket_jobs.append((self.block_range[first][2], self.block_range[last][3]))
         self.opt = FusedAdam(net, self.items, lr, betas)
         self.opt_stream = torch.cuda.Stream(device=dev)
-        # single-GPU: the whole step (q-sample .. Adam) is captured as one hipGraph and replayed (host launch cost
-        # ~7 ms/step eager vs ~0).  Data-parallel runs stay eager (the RCCL exchange is issued from Python).
+        # Optional (SDM_TRAIN_GRAPH=1, single GPU): capture the whole step (q-sample .. Adam) as one hipGraph.  Off by
+        # default: on ROCm 7.2 replaying the ~500-node multi-stream graph measured SLOWER than eager launching
+        # (10.1 vs 9.3 ms/step, MI355X, batch 4 64x64) -- the eager step is GPU-bound (host enqueue 7.5 ms/step).
         import os
         if use_graph is None:
-            use_graph = os.environ.get("SDM_TRAIN_GRAPH", "1") != "0"
+            use_graph = os.environ.get("SDM_TRAIN_GRAPH", "0") == "1"
         self.use_graph = bool(use_graph) and self.world == 1
         self.graph, self.g_key, self.hyper = None, None, None
         self.gen = torch.Generator(device=dev)
