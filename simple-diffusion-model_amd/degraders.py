@@ -18,14 +18,21 @@ class _TabulatedSchedule(nn.Module):
 
     def _install(self, lo, beta, alpha, abar):
         self._lo = lo
-        self.register_buffer("beta", beta.float(), persistent=False)
-        self.register_buffer("alpha", alpha.float(), persistent=False)
-        self.register_buffer("alpha_cumulative_prod", abar.float(), persistent=False)
+        # master tables stay on the host; per-device copies are made once and never moved or freed (a captured
+        # hipGraph may hold their addresses)
+        self.beta, self.alpha, self.alpha_cumulative_prod = beta.float(), alpha.float(), abar.float()
+        self._per_device = {}
 
     def _tables(self, device):
-        if self.beta.device != torch.device(device):
-            self.to(device)
-        return self.beta, self.alpha, self.alpha_cumulative_prod
+        device = torch.device(device)
+        if device.type == "cpu":
+            return self.beta, self.alpha, self.alpha_cumulative_prod
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        t = self._per_device.get(device)
+        if t is None:
+            t = self._per_device[device] = tuple(x.to(device) for x in (self.beta, self.alpha, self.alpha_cumulative_prod))
+        return t
 
     def get_timestep_params(self, step):
         b, a, ab = self._tables(step.device)
@@ -61,7 +68,6 @@ class NoiseDegradation(_TabulatedSchedule):
         beta = torch.linspace(start=beta_1, end=beta_T, steps=int(max_noise_step + 1))
         alpha = 1 - beta
         self._install(0, beta, alpha, torch.cumprod(alpha, dim=0))
-        self.to(device)
 
 
 class CosineNoiseDegradation(_TabulatedSchedule):
