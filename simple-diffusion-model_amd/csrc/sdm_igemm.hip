@@ -19,7 +19,6 @@
 struct IgemmLaunch {
   sdm_igemm_desc d;
   int splitk, ntn, kchunks;
-  long long ws_floats;   // split-K scratch: ws_floats partial sums followed by one ticket word per output tile
 };
 
 // One K-step = (tap, 32-channel chunk).  Per-tap state (row pointers, validity) is rebuilt only when the tap
@@ -302,63 +301,49 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
   // ---- epilogue
   const long long obo = b0 * d.o_bs0 + b1 * d.o_bs1;
   const long long rbo = b0 * d.r_bs0 + b1 * d.r_bs1;
-  bool finish = true;
-  if (L.splitk > 1) {
-    // Split-K: every workgroup adds its partial tile into the zero-filled scratch with memory-side float atomics,
-    // then takes a ticket; the workgroup that draws the last ticket of a tile finishes it below.  Only atomics
-    // touch the scratch (adds, then exchange-with-zero by the finisher), so no cache-visibility assumption is made,
-    // and the scratch and the ticket words are left zero for the next launch.
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * TN * 32 + j * 32 + l31;
-        if (col >= N) continue;
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + l31;
+      if (col >= N) continue;
+      const float bias = d.bias ? d.bias[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long long orow = s_orow[wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
-          if (orow >= 0) atomicAdd(&d.ws[orow * N + col], acc[i][j][r]);
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long long orow = s_orow[row];
+        if (orow < 0) continue;
+        float v = acc[i][j][r];
+        if (L.splitk > 1) {
+          atomicAdd(&d.ws[orow * N + col], v);
+          continue;
         }
+        v = v * d.alpha + bias;
+        if (d.out_preact) d.out_preact[obo + orow * d.ldo + col] = v;
+        v = sdm_act(v, d.act);
+        if (d.res) v += d.res[rbo + orow * d.ldres + col];
+        if (d.res2) v += d.res2[orow * d.ldres2 + col];
+        if (d.dact_z && (d.dact_ncols == 0 || col < d.dact_ncols)) v *= sdm_dsilu(d.dact_z[orow * d.ldz + col]);
+        d.out[obo + orow * d.ldo + col] = v;
       }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's adds have been performed
-    __syncthreads();
-    int* s_flag = (int*)As;
-    if (tid == 0) {
-      unsigned* ticket = (unsigned*)(d.ws + L.ws_floats) + (size_t)phase * gridDim.x + blockIdx.x;
-      const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = prev == (unsigned)(L.splitk - 1);
-      if (last) __hip_atomic_exchange(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *s_flag = last;
     }
-    __syncthreads();
-    finish = *s_flag != 0;
   }
-  if (finish) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * TN * 32 + j * 32 + l31;
-        if (col >= N) continue;
-        const float bias = d.bias ? d.bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const long long orow = s_orow[row];
-          if (orow < 0) continue;
-          float v = acc[i][j][r];
-          if (L.splitk > 1)
-            v = __hip_atomic_exchange(&d.ws[orow * N + col], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          v = v * d.alpha + bias;
-          if (d.out_preact) d.out_preact[obo + orow * d.ldo + col] = v;
-          v = sdm_act(v, d.act);
-          if (d.res) v += d.res[rbo + orow * d.ldres + col];
-          if (d.res2) v += d.res2[orow * d.ldres2 + col];
-          if (d.dact_z && (d.dact_ncols == 0 || col < d.dact_ncols)) v *= sdm_dsilu(d.dact_z[orow * d.ldz + col]);
-          d.out[obo + orow * d.ldo + col] = v;
-        }
-      }
-    }
+}
+
+// Finishes a split-K contraction: ws holds raw sums indexed [out row][N].
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const sdm_igemm_desc d, long long rows) {
+  const long long total = rows * d.N;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long orow = e / d.N;
+    const int col = (int)(e - orow * d.N);
+    float v = d.ws[e] * d.alpha + (d.bias ? d.bias[col] : 0.f);
+    d.ws[e] = 0.f;  // leave the scratch zero-filled for the next split-K launch
+    if (d.out_preact) d.out_preact[orow * d.ldo + col] = v;
+    v = sdm_act(v, d.act);
+    if (d.res) v += d.res[orow * d.ldres + col];
+    if (d.res2) v += d.res2[orow * d.ldres2 + col];
+    if (d.dact_z && (d.dact_ncols == 0 || col < d.dact_ncols)) v *= sdm_dsilu(d.dact_z[orow * d.ldz + col]);
+    d.out[orow * d.ldo + col] = v;
   }
 }
 
@@ -450,7 +435,7 @@ static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* w
   }
   *cfg = bc;
   *splitk = bs;
-  *ws_need = bs > 1 ? ((size_t)out_rows * N + (size_t)cdiv(M, kCfgs[bc].bm) * cdiv(N, kCfgs[bc].bn) * d->nphase + 64) * sizeof(float) : 0;
+  *ws_need = bs > 1 ? (size_t)out_rows * N * sizeof(float) : 0;
 }
 
 extern "C" size_t sdm_igemm_workspace_bytes(const sdm_igemm_desc* d) {
@@ -491,7 +476,7 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
                     (d->a.p1 == nullptr || (aligned16(d->a.p1) && d->a.ld1 % 4 == 0));
   const bool vecB = aligned16(d->b) && d->ldb % 4 == 0 && d->b_tap_stride % 4 == 0 && d->b_bs0 % 4 == 0 && d->b_bs1 % 4 == 0;
   const bool vec = vecA && vecB && d->K % 4 == 0 && (!d->b_kmajor || d->N % 4 == 0);
-  L.ws_floats = (long long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo * d->N;
+  const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
   const int ntm = cdiv(d->M, kCfgs[cfg].bm);
   L.ntn = cdiv(d->N, kCfgs[cfg].bn);
   const bool km = d->b_kmajor != 0;
@@ -500,7 +485,16 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
   else if (cfg == 1) rc = dispatch_igemm<64, 64, 2, 2>(L, ntm, km, vec, aff, st);
   else if (cfg == 2) rc = dispatch_igemm<32, 128, 1, 4>(L, ntm, km, vec, aff, st);
   else rc = dispatch_igemm<128, 64, 2, 2>(L, ntm, km, vec, aff, st);
-  return rc;
+  if (rc != SDM_OK) return rc;
+  if (L.splitk > 1) {
+    const long long total = (long long)out_rows * d->N;
+    int grid = (int)((total + 1023) / 1024);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, st, *d, (long long)out_rows);
+    SDM_CHECK_LAUNCH("splitk_epilogue");
+  }
+  return SDM_OK;
 }
 
 // --------------------------------------------------------------------------------------------
