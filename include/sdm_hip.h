@@ -267,6 +267,15 @@ int sdm_ddpm_update(float* x, const float* eps, const float* z, const float* coe
  * x is advanced to x_{t-1} only when update_flag != 0 (the reference skips the update on the last step). */
 int sdm_ddim_update(float* x, const float* eps, const float* coef, float* x0_out, size_t n, sdm_stream_t s);
 
+/* Cold-diffusion update of the super-resolution sampler (diffusion_sampling_algorithms.py:187-209):
+ *   x <- x - (c0*x0 + c1*noise) + (c2*x0 + c3*noise),  coef (DEVICE, 5 floats) = {sqrt(abar_t), sqrt(1-abar_t),
+ *   sqrt(abar_tm1), sqrt(1-abar_tm1), update_flag}; skipped when update_flag == 0 (last step). */
+int sdm_cold_update(float* x, const float* x0_hat, const float* noise, const float* coef, size_t n, sdm_stream_t s);
+/* F.interpolate(mode="area") on NCHW fp32 == adaptive average pooling (train_SR_diffusion.py:321-328): output pixel
+ * (i,j) averages input rows [floor(i*Hin/Hout), ceil((i+1)*Hin/Hout)) x the same for columns; integer
+ * down-scaling is block averaging, integer up-scaling is pixel replication. */
+int sdm_area_resize(const float* x, float* out, int planes, int Hin, int Win, int Hout, int Wout, sdm_stream_t s);
+
 /* Step-table cursor for a hipGraph-captured sampling step: t_cur[0] = t_table[*cursor];
  * coef_cur[0..ncoef) = coef_table[*cursor][0..ncoef); ++*cursor (saturating at nsteps-1).  With it the captured
  * graph (advance -> U-Net forward -> update) is parameter-free and is simply replayed once per denoise step

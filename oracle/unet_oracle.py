@@ -331,6 +331,31 @@ def ddim_sample(P, cfg, sched, x_t, min_noise=1, max_noise=1000, step=10, labels
     return (x0 if steps[-1] == 1 else x_t), traj
 
 
+def cold_sample(P, cfg, sched, x_t, noise, cond_img, min_noise=1, max_noise=1000, step=10, labels=None):
+    """diffusion_sampling_algorithms.py:150-217 (x0-prediction sampler of the SR path)."""
+    steps = ddim_steps(min_noise, max_noise, step)
+    with torch.no_grad():
+        for c, s in enumerate(steps):
+            t = torch.tensor([s])
+            x0 = unet_forward(P, cfg, torch.cat((x_t, cond_img), dim=1) if cond_img is not None else x_t, t, labels)
+            if c < len(steps) - 1:
+                tm1 = torch.tensor([steps[c + 1]])
+                x_t = x_t - q_sample(sched, x0, t, noise) + q_sample(sched, x0, tm1, noise)
+    return x0
+
+
+def area_resize(x, size):
+    """F.interpolate(mode="area") (train_SR_diffusion.py:321-328)."""
+    return F.interpolate(x, size=size, mode="area")
+
+
+def sr_batch(sched, x0, t, eps, lr_dim, sr_dim, cond_t):
+    """(network input, regression target) of the SR training step (train_SR_diffusion.py:318-374)."""
+    lr = area_resize(area_resize(x0, (lr_dim, lr_dim)), (sr_dim, sr_dim))
+    x_in = torch.cat((q_sample(sched, x0, t, eps), q_sample(sched, lr, torch.tensor([cond_t]), eps)), dim=1)
+    return x_in, x0 - lr
+
+
 # --------------------------------------------------------------------------- #
 # training step (train_diffusion.py:307-366)
 # --------------------------------------------------------------------------- #

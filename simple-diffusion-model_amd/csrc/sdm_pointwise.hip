@@ -955,6 +955,47 @@ extern "C" int sdm_ddim_update(float* x, const float* eps, const float* coef, fl
   return SDM_OK;
 }
 
+__global__ void cold_update_kernel(float* x, const float* x0, const float* nz, const float* coef, size_t n) {
+  const float a = coef[0], b = coef[1], c = coef[2], d = coef[3];
+  if (coef[4] == 0.f) return;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v0 = x0[i], e = nz[i];
+    x[i] = x[i] - (a * v0 + b * e) + (c * v0 + d * e);
+  }
+}
+extern "C" int sdm_cold_update(float* x, const float* x0_hat, const float* noise, const float* coef, size_t n,
+                               sdm_stream_t s) {
+  SDM_CHECK_ARG(x && x0_hat && noise && coef && n > 0, "cold_update: bad args");
+  hipLaunchKernelGGL(cold_update_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, x0_hat, noise, coef, n);
+  SDM_CHECK_LAUNCH("cold_update");
+  return SDM_OK;
+}
+
+__global__ void area_resize_kernel(const float* __restrict__ x, float* __restrict__ out, long long planes, int Hin, int Win,
+                                   int Hout, int Wout) {
+  const long long total = planes * Hout * Wout;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int j = (int)(e % Wout);
+    const int i = (int)((e / Wout) % Hout);
+    const long long pl = e / ((long long)Wout * Hout);
+    const int y0 = (int)(((long long)i * Hin) / Hout), y1 = (int)((((long long)(i + 1)) * Hin + Hout - 1) / Hout);
+    const int x0 = (int)(((long long)j * Win) / Wout), x1 = (int)((((long long)(j + 1)) * Win + Wout - 1) / Wout);
+    const float* p = x + pl * Hin * Win;
+    float acc = 0.f;
+    for (int yy = y0; yy < y1; ++yy)
+      for (int xx = x0; xx < x1; ++xx) acc += p[(long long)yy * Win + xx];
+    out[e] = acc / (float)((y1 - y0) * (x1 - x0));
+  }
+}
+extern "C" int sdm_area_resize(const float* x, float* out, int planes, int Hin, int Win, int Hout, int Wout, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && out && planes > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "area_resize: bad args");
+  const size_t n = (size_t)planes * Hout * Wout;
+  hipLaunchKernelGGL(area_resize_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, out, (long long)planes, Hin, Win,
+                     Hout, Wout);
+  SDM_CHECK_LAUNCH("area_resize");
+  return SDM_OK;
+}
+
 __global__ void step_advance_kernel(int* cursor, const int64_t* t_table, const float* coef_table, int ncoef, int nsteps,
                                     int64_t* t_cur, float* coef_cur) {
   const int c = *cursor;

@@ -151,30 +151,39 @@ def ddim_sampling(diffusion_net, noise_degradation, x_t, min_noise=1, max_noise=
 
 
 def cold_diffusion_sampling(diffusion_net, noise_degradation, x_t, noise, min_noise=1, max_noise=1_000, cond_img=None,
-                            labels_tensor=None, skip_step_size=10, device="cpu", log=print):
-    """x0-prediction sampler of the SR path (reference :150-217): x_t <- x_t - D(x0_hat, t) + D(x0_hat, t-1)."""
+                            labels_tensor=None, skip_step_size=10, device="cpu", log=print, *, use_graph=None):
+    """x0-prediction sampler of the SR path (reference :150-217): x_t <- x_t - D(x0_hat, t) + D(x0_hat, t-1) with
+    D(x0, t) = sqrt(abar_t) x0 + sqrt(1-abar_t) noise; both degradations and the update are one fused kernel and the
+    step is replayed as a hipGraph like the other samplers.  Returns the last x0 estimate."""
     _require_cuda(x_t)
     dev = x_t.device
     diffusion_net.eval()
     steps = list(range(max_noise, min_noise - 1, -skip_step_size))
     if min_noise not in steps:
         steps = steps + [min_noise]
+    abar = noise_degradation.get_timestep_params(torch.tensor(steps))[2].cpu()
+    abar_next = torch.cat((abar[1:], abar[-1:]))
+    upd = torch.ones_like(abar)
+    upd[-1] = 0.0                                                    # no update after the last reconstruction
+    coef = torch.stack((abar ** 0.5, (1 - abar) ** 0.5, abar_next ** 0.5, (1 - abar_next) ** 0.5, upd), dim=1)
     if cond_img is not None:
-        cond_img = cond_img.to(dev)
+        cond_img = cond_img.to(dev).float().contiguous()
     if labels_tensor is not None:
         labels_tensor = labels_tensor.to(dev)
-    x_t = x_t.detach().float().contiguous().clone()
     noise = noise.to(dev).float().contiguous()
+    r = _StepRunner(diffusion_net, x_t, steps, coef, cond_img, labels_tensor, None, _use_graph(use_graph))
+    x0_hat = torch.empty((x_t.shape[0], diffusion_net.out_channel) + tuple(x_t.shape[2:]), dtype=torch.float32, device=dev)
+
+    def body():
+        r.advance()
+        x0_hat.copy_(r.eps())                                        # the net predicts x0 here
+        ops.cold_update(r.x, x0_hat, noise, r.coef_cur)
+
+    def on_step(i):
+        if i < len(steps) - 1:
+            printProgressBar(iteration=max_noise - steps[i], total=max_noise - min_noise, prefix='Iterations:',
+                             suffix='Complete', length=50, log=log)
+
     with torch.no_grad():
-        for count, s in enumerate(steps):
-            t = torch.tensor([s], device=dev)
-            xin = x_t if cond_img is None else torch.cat((x_t, cond_img), dim=1)
-            x0_hat = diffusion_net(xin, t, labels_tensor)
-            if count < len(steps) - 1:
-                tm1 = torch.tensor([steps[count + 1]], device=dev)
-                x_t_hat = noise_degradation(img=x0_hat, steps=t, eps=noise)
-                x_tm1_hat = noise_degradation(img=x0_hat, steps=tm1, eps=noise)
-                x_t = x_t - x_t_hat + x_tm1_hat
-                printProgressBar(iteration=max_noise - s, total=max_noise - min_noise, prefix='Iterations:',
-                                 suffix='Complete', length=50, log=log)
+        r.run(body, on_step)
     return x0_hat

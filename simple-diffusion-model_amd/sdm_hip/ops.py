@@ -574,6 +574,20 @@ def ddim_update(x, eps, coef, x0_out=None):
     lib.call("sdm_ddim_update", _p(x), _p(eps), _p(coef), _p(x0_out), x.numel(), _stream())
 
 
+def cold_update(x, x0_hat, noise, coef):
+    lib.call("sdm_cold_update", _p(x), _p(x0_hat), _p(noise), _p(coef), x.numel(), _stream())
+
+
+def area_resize(x, size):
+    """F.interpolate(x, size=size, mode="area") for NCHW fp32 on the device."""
+    n, c, h, w = x.shape
+    ho, wo = size
+    x = x.float().contiguous()
+    out = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
+    lib.call("sdm_area_resize", _p(x), _p(out), n * c, h, w, ho, wo, _stream())
+    return out
+
+
 class LinearBank:
     """The y_scale projections of every AdaGN in the net, evaluated in ONE launch (sdm_linear_multi) and
     differentiated w.r.t. the shared embedding in ONE launch (sdm_linear_multi_bwd_dx).  Holds the device job

@@ -86,7 +86,10 @@ class FusedAdam:
 
 class DiffusionTrainer:
     def __init__(self, net, schedule, lr=2e-5, betas=(0.5, 0.999), min_noise_step=1, max_actual_noise_step=1000,
-                 bucket_mb=64, process_group=None, seed=None, use_graph=None):
+                 bucket_mb=64, process_group=None, seed=None, use_graph=None, sr=None):
+        """``sr=(lr_dim, sr_dim, cond_t)`` switches to the super-resolution objective of train_SR_diffusion.py:318-374:
+        the net sees cat(q(x0, t), q(lowres(x0), cond_t)) and regresses x0 - lowres(x0)."""
+        self.sr = sr
         self.net, self.schedule = net, schedule
         self.min_t, self.max_t = min_noise_step, max_actual_noise_step
         self.pg = process_group
@@ -153,12 +156,19 @@ class DiffusionTrainer:
     def _body(self, x0, labels, eps, t, hyper=None):
         abar = self.schedule.alpha_bar_of(t)
         x_t = ops.q_sample(x0, eps, abar)
+        target = eps
+        if self.sr is not None:
+            lr_dim, sr_dim, cond_t = self.sr
+            low = ops.area_resize(ops.area_resize(x0, (lr_dim, lr_dim)), (sr_dim, sr_dim))
+            abar_c = self.schedule.alpha_bar_of(torch.full((x0.shape[0],), int(cond_t), dtype=torch.int64, device=self.dev))
+            x_t = torch.cat((x_t, ops.q_sample(low, eps, abar_c)), dim=1)
+            target = x0 - low
         self.flat.zero_()                               # backward accumulates (split-K atomics, column sums)
         self.reducer.begin_step()
         self._hyper = hyper
         self.net._block_done_hook = self._bucket_closed
         try:
-            loss, _ = self.net.loss_and_grads(x_t, t, labels, eps, grads=self.grads)
+            loss, _ = self.net.loss_and_grads(x_t, t, labels, target, grads=self.grads)
         finally:
             self.net._block_done_hook = None
         self.reducer.pending = []

@@ -291,9 +291,62 @@ def train_case():
     print("train losses", losses)
 
 
+def sr_case():
+    """Super-resolution path of the reference: two Adam steps of the train_SR_diffusion.py step body (:318-374) and a
+    cold_diffusion_sampling run (diffusion_sampling_algorithms.py:150-217) with a conditional low-res image."""
+    import torch.nn.functional as F
+    cfg = O.full_cfg(MODEL_CASES["sr_recon"][0])
+    P = O.seeded_params(cfg, seed=3, gain=1.8)
+    m = ref_model(cfg, P)
+    lin = RD.NoiseDegradation(5e-3, 9e-3, 1000)
+    g = torch.Generator().manual_seed(31)
+    out = {}
+    # sampler first (fresh weights)
+    lr_img = torch.randn(2, 3, 4, 4, generator=g)
+    noise = torch.randn(2, 3, 8, 8, generator=g)
+    up = F.interpolate(lr_img, size=(8, 8), mode="area")
+    cond = lin(img=up, steps=torch.tensor([250]), eps=noise)
+    m.eval()
+    quiet = lambda *a, **k: None
+    x0 = RS.cold_diffusion_sampling(m, lin, 1 * noise, noise, min_noise=1, max_noise=1000, cond_img=cond,
+                                    skip_step_size=250, log=quiet)
+    out["samp/lr_img"], out["samp/noise"], out["samp/up"], out["samp/cond"], out["samp/x0"] = (
+        lr_img.numpy(), noise.numpy(), up.numpy(), cond.numpy(), x0.detach().numpy())
+    # area interpolation goldens (down by 2, up by 2, non-integer ratio)
+    a = torch.randn(2, 3, 12, 8, generator=g)
+    out["area/x"] = a.numpy()
+    for tag, size in (("down", (6, 4)), ("up", (24, 16)), ("odd", (5, 3)), ("mixed", (9, 12))):
+        out[f"area/{tag}"] = F.interpolate(a, size=size, mode="area").numpy()
+    # training
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=2e-3, betas=(0.5, 0.999))
+    losses = []
+    for i in range(2):
+        tr = torch.randn(4, 3, 8, 8, generator=g)
+        eps = torch.randn(4, 3, 8, 8, generator=g)
+        t = torch.randint(1, 1000, (4,), generator=g)
+        lr = F.interpolate(F.interpolate(tr, size=(4, 4), mode="area"), size=(8, 8), mode="area")
+        opt.zero_grad()
+        x_in = torch.cat((lin(tr, t, eps), lin(lr, torch.tensor([250]), eps)), dim=1)
+        loss = F.mse_loss(m(x_in, t, None), tr - lr)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        out[f"train/x0_{i}"], out[f"train/eps_{i}"], out[f"train/t_{i}"] = tr.numpy(), eps.numpy(), t.numpy()
+    out["train/losses"] = np.array(losses)
+    for i, (k, v) in enumerate(m.state_dict().items()):
+        v = v.double().flatten()
+        idx = sample_idx(v.numel(), i)
+        out[f"pidx/{k}"] = idx
+        out[f"pval/{k}"] = v[idx].float().numpy()
+    np.savez(os.path.join(HERE, "sr_path.npz"), **out)
+    print("sr losses", losses)
+
+
 if __name__ == "__main__":
     for name, (cfg, N, H, W, gain) in MODEL_CASES.items():
         model_case(name, cfg, N, H, W, gain)
     block_cases()
     schedule_and_sampler_cases()
     train_case()
+    sr_case()

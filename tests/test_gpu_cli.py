@@ -56,3 +56,40 @@ def test_train_then_generate(tmp_path):
                            cwd=PKG, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
     assert len(list((dest / "plots").glob("*.jpg"))) == 2
+
+
+def test_sr_train_then_generate(tmp_path):
+    """Super-resolution command lines (train_SR_diffusion.py / generate_sr_images_diffusion.py), 8 -> 16 pixels."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import numpy as np
+    out = tmp_path / "run"
+    cfg = dict(checkpoint_steps=100, lr_steps=1000, max_epoch=1, plot_img_count=2, use_conditional=False, flip_imgs=False,
+               dataset_path="synthetic:8:3:16:16", out_dir=str(out), model_checkpoint=None, config_checkpoint=None,
+               load_diffusion_optim=False, diffusion_lr=2e-4, batch_size=4, noise_scheduler="COSINE",
+               min_noise_step=1, max_noise_step=1000, max_actual_noise_step=1000, skip_step=250, lr_dim=8, sr_dim=16,
+               cond_t=250, in_channel=6, out_channel=3, num_layers=2, num_resnet_block=1, attn_layers=[1], attn_heads=1,
+               attn_dim_per_head=None, time_dim=32, cond_dim=None, min_channel=32, max_channel=64, img_recon=True, seed=3)
+    cfg_path = tmp_path / "train_sr.json"
+    cfg_path.write_text(json.dumps(cfg))
+    env = dict(os.environ, PYTHONPATH=PKG)
+    r = subprocess.run([sys.executable, os.path.join(PKG, "train_SR_diffusion.py"), "-c", str(cfg_path), "--device", "cuda"],
+                       cwd=PKG, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ck = out / "checkpoint"
+    assert (ck / "diffusion_2.pt").exists() and (out / "plots" / "diffusion_plot_0.jpg").exists()
+    md = dict(model_name="diffusion_2.pt", img_C=3, img_H=16, img_W=16, in_channel=6, out_channel=3, num_layers=2,
+              num_resnet_block=1, attn_layers=[1], attn_heads=1, attn_dim_per_head=None, time_dim=32, cond_dim=None,
+              min_channel=32, max_channel=64, image_recon=True, max_noise=1000, min_noise=1, noise_scheduler="COSINE",
+              cond_t=250)
+    (ck / "config.json").write_text(json.dumps({"models": [md]}))
+    from PIL import Image
+    lr_path = tmp_path / "low.png"
+    Image.fromarray((np.random.default_rng(0).random((8, 8, 3)) * 255).astype("uint8")).save(lr_path)
+    dest = tmp_path / "gen"
+    dest.mkdir()
+    r = subprocess.run([sys.executable, os.path.join(PKG, "generate_sr_images_diffusion.py"), "-c", str(ck / "config.json"),
+                        "--device", "cuda", "-s", "7", "-d", str(dest), "--lr_img_path", str(lr_path), "--cold_step_size", "250"],
+                       cwd=PKG, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(list((dest / "plots").glob("*.jpg"))) == 1

@@ -469,3 +469,62 @@ def test_baseline_shapes_vs_oracle(dev, O, name, over, n, res):
         y = net(x.cuda(), t.cuda(), cond.cuda() if cond is not None else None)
     assert torch.allclose(y.cpu(), ref, rtol=RTOL, atol=ATOL), (name, float((y.cpu() - ref).abs().max()))
     assert rel(y, ref) < 2e-5, (name, rel(y, ref))
+
+
+# ------------------------------------------------------------------------------------------------
+# super-resolution path: area interpolation, cold sampler, SR training step
+# ------------------------------------------------------------------------------------------------
+SR_CFG = dict(num_resnet_blocks=1, in_channel=6, out_channel=3, time_dim=32, cond_dim=None, num_layers=2, attn_layers=[0, 1],
+              num_heads=1, dim_per_head=None, min_channel=32, max_channel=32, image_recon=True)
+
+
+def test_area_resize_golden(dev):
+    from sdm_hip import ops
+    g = np.load(os.path.join(GOLDEN, "sr_path.npz"))
+    x = T(g["area/x"]).cuda()
+    for tag, size in (("down", (6, 4)), ("up", (24, 16)), ("odd", (5, 3)), ("mixed", (9, 12))):
+        got = ops.area_resize(x, size)
+        assert torch.allclose(got.cpu(), T(g[f"area/{tag}"]), rtol=1e-6, atol=1e-6), tag
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_cold_sampler_golden(dev, O, use_graph):
+    import degraders as D
+    import diffusion_sampling_algorithms as S
+    from models.U_Net import U_Net
+    from sdm_hip import ops
+    g = np.load(os.path.join(GOLDEN, "sr_path.npz"))
+    cfg = O.full_cfg(SR_CFG)
+    net = U_Net(**cfg)
+    net.load_state_dict(O.seeded_params(cfg, seed=3, gain=1.8), strict=True)
+    net = net.cuda()
+    lin = D.NoiseDegradation(5e-3, 9e-3, 1000, "cuda")
+    noise = T(g["samp/noise"]).cuda()
+    up = ops.area_resize(T(g["samp/lr_img"]).cuda(), (8, 8))
+    cond = lin(up, torch.tensor([250], device="cuda"), noise)
+    assert torch.allclose(cond.cpu(), T(g["samp/cond"]), rtol=1e-5, atol=1e-6)
+    x0 = S.cold_diffusion_sampling(net, lin, 1 * noise, noise, min_noise=1, max_noise=1000, cond_img=cond, skip_step_size=250,
+                                   device="cuda", log=lambda *a, **k: None, use_graph=use_graph)
+    ref = T(g["samp/x0"])
+    assert torch.allclose(x0.cpu(), ref, rtol=1e-3, atol=1e-4), float((x0.cpu() - ref).abs().max())
+
+
+def test_sr_training_steps_golden(dev, O):
+    import degraders as D
+    from models.U_Net import U_Net
+    from sdm_hip.trainer import DiffusionTrainer
+    g = np.load(os.path.join(GOLDEN, "sr_path.npz"))
+    cfg = O.full_cfg(SR_CFG)
+    net = U_Net(**cfg)
+    net.load_state_dict(O.seeded_params(cfg, seed=3, gain=1.8), strict=True)
+    net = net.cuda()
+    tr = DiffusionTrainer(net, D.NoiseDegradation(5e-3, 9e-3, 1000, "cuda"), lr=2e-3, sr=(4, 8, 250))
+    for i in range(2):
+        loss = tr.step(T(g[f"train/x0_{i}"]).cuda(), None, eps=T(g[f"train/eps_{i}"]).cuda(), t=T(g[f"train/t_{i}"]).cuda())
+        assert abs(float(loss) - float(g["train/losses"][i])) < 5e-5, (i, float(loss))
+    bad = []
+    for k, v in net.state_dict().items():
+        got = v.detach().double().cpu().contiguous().flatten()[T(g[f"pidx/{k}"])]
+        if not torch.allclose(got, T(g[f"pval/{k}"]).double(), rtol=1e-3, atol=2e-4):
+            bad.append((k, float((got - T(g[f"pval/{k}"]).double()).abs().max())))
+    assert not bad, bad[:8]

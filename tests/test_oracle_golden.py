@@ -151,3 +151,30 @@ def test_training_steps():
     for k, v in tr.P.items():
         got = v.detach().double().flatten()[T(g[f"pidx/{k}"])]
         assert torch.allclose(got, T(g[f"pval/{k}"]).double(), rtol=1e-3, atol=2e-5), k
+
+
+def test_sr_path():
+    """Area interpolation, the cold sampler and the SR training step against the reference's SR goldens."""
+    g = load("sr_path.npz")
+    cfg = O.full_cfg(dict(num_resnet_blocks=1, in_channel=6, out_channel=3, time_dim=32, cond_dim=None, num_layers=2,
+                          attn_layers=[0, 1], num_heads=1, dim_per_head=None, min_channel=32, max_channel=32,
+                          image_recon=True))
+    P = O.seeded_params(cfg, seed=3, gain=1.8)
+    lin = O.LinearSchedule(5e-3, 9e-3, 1000)
+    noise, up = T(g["samp/noise"]), O.area_resize(T(g["samp/lr_img"]), (8, 8))
+    assert torch.allclose(up, T(g["samp/up"]))
+    cond = O.q_sample(lin, up, torch.tensor([250]), noise)
+    assert torch.allclose(cond, T(g["samp/cond"]), rtol=1e-6, atol=1e-6)
+    x0 = O.cold_sample(P, cfg, lin, noise.clone(), noise, cond, 1, 1000, 250)
+    assert torch.allclose(x0, T(g["samp/x0"]), rtol=1e-4, atol=1e-5)
+    tr = O.OracleTrainer(P, cfg, lin, lr=2e-3)
+    for i in range(2):
+        x_in, target = O.sr_batch(lin, T(g[f"train/x0_{i}"]), T(g[f"train/t_{i}"]), T(g[f"train/eps_{i}"]), 4, 8, 250)
+        tr.opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(O.unet_forward(tr.P, cfg, x_in, T(g[f"train/t_{i}"])), target)
+        loss.backward()
+        tr.opt.step()
+        assert abs(float(loss) - float(g["train/losses"][i])) < 2e-5
+    for k, v in tr.P.items():
+        got = v.detach().double().flatten()[T(g[f"pidx/{k}"])]
+        assert torch.allclose(got, T(g[f"pval/{k}"]).double(), rtol=1e-3, atol=2e-5), k
