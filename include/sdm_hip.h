@@ -267,6 +267,10 @@ int sdm_ddpm_update(float* x, const float* eps, const float* z, const float* coe
  * x is advanced to x_{t-1} only when update_flag != 0 (the reference skips the update on the last step). */
 int sdm_ddim_update(float* x, const float* eps, const float* coef, float* x0_out, size_t n, sdm_stream_t s);
 
+/* Classifier-free guidance (build-side extension, BASELINE config 3; not in the reference): the U-Net is evaluated once
+ * on a 2N batch [conditional | unconditional(all-zero label)]; out[i] = e_u[i] + w*(e_c[i] - e_u[i]). */
+int sdm_cfg_combine(const float* eps_2n, float* out, float w, size_t n_half, sdm_stream_t s);
+
 /* Cold-diffusion update of the super-resolution sampler (diffusion_sampling_algorithms.py:187-209):
  *   x <- x - (c0*x0 + c1*noise) + (c2*x0 + c3*noise),  coef (DEVICE, 5 floats) = {sqrt(abar_t), sqrt(1-abar_t),
  *   sqrt(abar_tm1), sqrt(1-abar_tm1), update_flag}; skipped when update_flag == 0 (last step). */

@@ -955,6 +955,19 @@ extern "C" int sdm_ddim_update(float* x, const float* eps, const float* coef, fl
   return SDM_OK;
 }
 
+__global__ void cfg_combine_kernel(const float* e, float* out, float w, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float c = e[i], u = e[n + i];
+    out[i] = u + w * (c - u);
+  }
+}
+extern "C" int sdm_cfg_combine(const float* eps_2n, float* out, float w, size_t n_half, sdm_stream_t s) {
+  SDM_CHECK_ARG(eps_2n && out && n_half > 0, "cfg_combine: bad args");
+  hipLaunchKernelGGL(cfg_combine_kernel, dim3(ew_grid(n_half)), dim3(256), 0, (hipStream_t)s, eps_2n, out, w, n_half);
+  SDM_CHECK_LAUNCH("cfg_combine");
+  return SDM_OK;
+}
+
 __global__ void cold_update_kernel(float* x, const float* x0, const float* nz, const float* coef, size_t n) {
   const float a = coef[0], b = coef[1], c = coef[2], d = coef[3];
   if (coef[4] == 0.f) return;

@@ -8,7 +8,9 @@ device-resident tables through a cursor the graph itself advances, so a replay n
 Coefficient tables are computed with the reference's own float32 expressions.
 
 Extra keyword-only arguments (not in the reference): ``noise`` injects the per-step z tensors (trajectory
-parity tests; GPU and CPU generators differ), ``use_graph`` forces/disables hipGraph capture.
+parity tests; GPU and CPU generators differ), ``use_graph`` forces/disables hipGraph capture, ``cfg_scale`` turns on
+classifier-free guidance (BASELINE config 3): the net runs once per step on [x | x] with [labels | 0] and the two
+halves are blended as e_u + w (e_c - e_u).
 """
 import os
 
@@ -27,9 +29,15 @@ def _use_graph(flag):
 class _StepRunner:
     """Owns the static buffers of one sampling run and replays the captured step."""
 
-    def __init__(self, net, x_t, t_steps, coef, cond_img, labels, noise, use_graph):
+    def __init__(self, net, x_t, t_steps, coef, cond_img, labels, noise, use_graph, cfg_scale=None):
         dev = x_t.device
         self.net, self.cond_img, self.labels, self.noise = net, cond_img, labels, noise
+        self.cfg_scale = cfg_scale
+        if cfg_scale is not None:
+            if labels is None:
+                raise ValueError("classifier-free guidance needs labels")
+            lab = labels if labels.dim() == 2 else labels[None, :].expand(x_t.shape[0], -1)
+            self.labels2 = torch.cat((lab.float(), torch.zeros_like(lab, dtype=torch.float32)), dim=0).contiguous()
         self.x = x_t.detach().to(torch.float32).contiguous().clone()
         self.nsteps, self.ncoef = len(t_steps), coef.shape[1]
         self.t_table = torch.tensor(t_steps, dtype=torch.int64, device=dev)
@@ -47,7 +55,11 @@ class _StepRunner:
 
     def eps(self):
         xin = self.x if self.cond_img is None else torch.cat((self.x, self.cond_img), dim=1)
-        return self.net(xin, self.t_cur, self.labels)
+        if self.cfg_scale is None:
+            return self.net(xin, self.t_cur, self.labels)
+        n = xin.shape[0]
+        e2 = self.net(torch.cat((xin, xin), dim=0), self.t_cur.expand(2 * n).contiguous(), self.labels2)
+        return ops.cfg_combine(e2, self.cfg_scale)
 
     def z(self):
         if self.noise is None:
@@ -85,7 +97,7 @@ def _require_cuda(x_t):
 
 
 def ddpm_sampling(diffusion_net, noise_degradation, x_t, min_noise=1, max_noise=1_000, cond_img=None,
-                  labels_tensor=None, device="cpu", log=print, *, noise=None, use_graph=None):
+                  labels_tensor=None, device="cpu", log=print, *, noise=None, use_graph=None, cfg_scale=None):
     _require_cuda(x_t)
     dev = x_t.device
     diffusion_net.eval()
@@ -101,7 +113,7 @@ def ddpm_sampling(diffusion_net, noise_degradation, x_t, min_noise=1, max_noise=
         labels_tensor = labels_tensor.to(dev)
     if noise is not None:
         noise = noise.to(dev).float().contiguous()
-    r = _StepRunner(diffusion_net, x_t, steps, coef, cond_img, labels_tensor, noise, _use_graph(use_graph))
+    r = _StepRunner(diffusion_net, x_t, steps, coef, cond_img, labels_tensor, noise, _use_graph(use_graph), cfg_scale)
 
     def body():
         r.advance()
@@ -117,7 +129,7 @@ def ddpm_sampling(diffusion_net, noise_degradation, x_t, min_noise=1, max_noise=
 
 
 def ddim_sampling(diffusion_net, noise_degradation, x_t, min_noise=1, max_noise=1_000, cond_img=None,
-                  labels_tensor=None, ddim_step_size=10, device="cpu", log=print, *, use_graph=None):
+                  labels_tensor=None, ddim_step_size=10, device="cpu", log=print, *, use_graph=None, cfg_scale=None):
     _require_cuda(x_t)
     dev = x_t.device
     diffusion_net.eval()
@@ -134,7 +146,7 @@ def ddim_sampling(diffusion_net, noise_degradation, x_t, min_noise=1, max_noise=
         cond_img = cond_img.to(dev)
     if labels_tensor is not None:
         labels_tensor = labels_tensor.to(dev)
-    r = _StepRunner(diffusion_net, x_t, steps, coef, cond_img, labels_tensor, None, _use_graph(use_graph))
+    r = _StepRunner(diffusion_net, x_t, steps, coef, cond_img, labels_tensor, None, _use_graph(use_graph), cfg_scale)
     x0 = torch.empty_like(r.x)
 
     def body():

@@ -29,6 +29,8 @@ _FLAGS = [
     (("-T", "--max_T"), dict(type=int, default=1_000, help="Max T of the noise schedule (ensembles).")),
     (("--cond_img_path",), dict(type=pathlib.Path, default=None, help="Conditional image, e.g. a doodle.")),
     (("-l", "--labels"), dict(nargs="*", type=float, default=None, help="Conditional labels.")),
+    # extension (not in the reference): classifier-free guidance weight; omit for the reference behaviour
+    (("--cfg_scale",), dict(type=float, default=None, help="Classifier-free guidance weight w (conditional models).")),
 ]
 
 _UNET_KEYS = dict(in_channel="in_channel", out_channel="out_channel", num_layers="num_layers",
@@ -105,7 +107,8 @@ def generate_images_diffusion(raw_args=None, log=print, cond_img=None, save_loca
             raise Exception("Failed to load model!")
         net.load_state_dict(ckpt["model"])
         common = dict(diffusion_net=net, noise_degradation=schedule, x_t=x_t, min_noise=md["min_noise"],
-                      max_noise=md["max_noise"], cond_img=cond_img, labels_tensor=labels, device=dev, log=log)
+                      max_noise=md["max_noise"], cond_img=cond_img, labels_tensor=labels, device=dev, log=log,
+                      cfg_scale=args["cfg_scale"] if labels is not None else None)
         x_t = ddim_sampling(ddim_step_size=args["ddim_step_size"], **common) if ddim else ddpm_sampling(**common)
 
     if not save_locally:

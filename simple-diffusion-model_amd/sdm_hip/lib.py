@@ -113,6 +113,7 @@ _PROTOS = {
     "sdm_q_sample": (_i, [fp, fp, fp, fp, _i, _sz, fp]),
     "sdm_ddpm_update": (_i, [fp, fp, fp, fp, _sz, fp]),
     "sdm_ddim_update": (_i, [fp, fp, fp, fp, _sz, fp]),
+    "sdm_cfg_combine": (_i, [fp, fp, _f, _sz, fp]),
     "sdm_cold_update": (_i, [fp, fp, fp, fp, _sz, fp]),
     "sdm_area_resize": (_i, [fp, fp, _i, _i, _i, _i, _i, fp]),
     "sdm_step_advance": (_i, [fp, fp, fp, _i, _i, fp, fp, fp]),

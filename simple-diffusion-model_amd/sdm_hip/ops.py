@@ -574,6 +574,14 @@ def ddim_update(x, eps, coef, x0_out=None):
     lib.call("sdm_ddim_update", _p(x), _p(eps), _p(coef), _p(x0_out), x.numel(), _stream())
 
 
+def cfg_combine(eps_2n, w):
+    """eps_2n: [2N, ...] = [conditional | unconditional]; returns e_u + w (e_c - e_u) of shape [N, ...]."""
+    n = eps_2n.shape[0] // 2
+    out = torch.empty((n,) + tuple(eps_2n.shape[1:]), dtype=torch.float32, device=eps_2n.device)
+    lib.call("sdm_cfg_combine", _p(eps_2n), _p(out), float(w), out.numel(), _stream())
+    return out
+
+
 def cold_update(x, x0_hat, noise, coef):
     lib.call("sdm_cold_update", _p(x), _p(x0_hat), _p(noise), _p(coef), x.numel(), _stream())
 

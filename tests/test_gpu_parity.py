@@ -528,3 +528,34 @@ def test_sr_training_steps_golden(dev, O):
         if not torch.allclose(got, T(g[f"pval/{k}"]).double(), rtol=1e-3, atol=2e-4):
             bad.append((k, float((got - T(g[f"pval/{k}"]).double()).abs().max())))
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_classifier_free_guidance_matches_two_pass_oracle(dev, O, use_graph):
+    """CFG is a build-side extension (no reference code): the 2N-batch implementation must equal two separate oracle
+    passes (label / all-zero label) blended as e_u + w (e_c - e_u), through a 3-step DDIM trajectory."""
+    import degraders as D
+    import diffusion_sampling_algorithms as S
+    cfg, net = narrow_net(O)
+    P = O.seeded_params(cfg, seed=3, gain=1.8)
+    g = torch.Generator().manual_seed(2)
+    xT = torch.randn(2, 3, 8, 8, generator=g)
+    labels = torch.tensor([0.0, 1.0, 0.0])
+    w = 3.0
+    sch = O.LinearSchedule(5e-3, 9e-3, 1000)
+    steps = O.ddim_steps(1, 401, 200)
+    x = xT.clone()
+    with torch.no_grad():
+        for c, s_ in enumerate(steps):
+            t = torch.tensor([s_])
+            ec = O.unet_forward(P, cfg, x, t, labels)
+            eu = O.unet_forward(P, cfg, x, t, torch.zeros(3))
+            e = eu + w * (ec - eu)
+            ab = sch.params(t)[2]
+            x0 = (1 / ab ** 0.5) * (x - (1 - ab) ** 0.5 * e)
+            if c < len(steps) - 1:
+                ab1 = sch.params(torch.tensor([steps[c + 1]]))[2]
+                x = ab1 ** 0.5 * x0 + (1 - ab1) ** 0.5 * e
+    out = S.ddim_sampling(net, D.NoiseDegradation(5e-3, 9e-3, 1000, "cuda"), xT.cuda(), 1, 401, labels_tensor=labels.cuda(),
+                          ddim_step_size=200, device="cuda", log=lambda *a, **k: None, use_graph=use_graph, cfg_scale=w)
+    assert torch.allclose(out.cpu(), x0, rtol=1e-3, atol=1e-4), float((out.cpu() - x0).abs().max())
