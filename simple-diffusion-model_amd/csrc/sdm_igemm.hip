@@ -330,6 +330,276 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
   }
 }
 
+// --------------------------------------------------------------------------------------------
+// LDS-DMA variant (no pending affine, 16-byte-aligned operands): operand tiles go global -> LDS directly with
+// global_load_lds_dwordx4 (no VGPR round trip, no select, no ds_write).  One wave-instruction writes 1 KiB
+// lane-linearly, i.e. 8 rows of 32 floats; rows are therefore unpadded and bank conflicts are avoided by an XOR
+// swizzle of the 16-byte chunk index with (row>>1)&7, applied to the per-lane SOURCE address and again on the
+// fragment read.  Out-of-image taps / rows read a 16-byte zero word instead.  NBUF LDS buffers form a ring: the
+// tile of K-step it+NBUF-1 is issued right after the barrier of step `it`, a counted s_waitcnt keeps the younger
+// tiles in flight across the barrier (one raw s_barrier per K-step).
+// --------------------------------------------------------------------------------------------
+__device__ float g_zero_chunk[4];
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, bool BKM, int NBUF>
+__global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
+  const sdm_igemm_desc& d = L.d;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int AIT = BM / 32, BIT = BN / 32;
+  constexpr int A_TILE = BM * BK;
+  constexpr int B_TILE = BN * BK;
+  constexpr int CPR = BN / 4, RPP = 256 / CPR;
+  constexpr int G = AIT + BIT;      // LDS-DMA instructions per thread per K-step
+  constexpr int PD = NBUF - 1;      // prefetch distance in K-steps
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;
+  float* Bs = smem + NBUF * A_TILE;
+  long long* s_orow = (long long*)(Bs + NBUF * B_TILE);
+  int* s_tap = (int*)(s_orow + BM);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
+  const int tile_n = blockIdx.x % L.ntn, tile_m = blockIdx.x / L.ntn;
+  const int phase = blockIdx.y / L.splitk, ks = blockIdx.y % L.splitk;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
+  const float* a0 = d.a.p0 + b0 * d.a_bs0 + b1 * d.a_bs1;
+  const float* a1 = d.a.p1;
+  const float* bw = d.b + b0 * d.b_bs0 + b1 * d.b_bs1;
+  const int HtWt = d.Ht * d.Wt;
+  const int K = d.K, N = d.N, csplit = d.a.csplit;
+  const int arow = tid >> 3;
+  // logical 16-byte chunk this lane fetches for its physical slot (tid&7): slot ^ ((row>>1)&7); rows arow+32i share it
+  const int cc4 = 4 * ((tid & 7) ^ ((arow >> 1) & 7));
+  const int sw_l = (l31 >> 1) & 7;  // swizzle of the fragment rows this lane reads
+  const float* zero = g_zero_chunk;
+
+  for (int r = tid; r < BM; r += 256) {
+    int m = m0 + r;
+    long long o = -1;
+    if (m < d.M) {
+      int n = m / HtWt, rem = m - n * HtWt;
+      int y = rem / d.Wt, x = rem - y * d.Wt;
+      int oy = y * d.ostride + d.ph_oy[phase], ox = x * d.ostride + d.ph_ox[phase];
+      if (oy < d.Ho && ox < d.Wo) o = ((long long)n * d.Ho + oy) * d.Wo + ox;
+    }
+    s_orow[r] = o;
+  }
+  if (tid < SDM_MAX_TAPS) {
+    s_tap[tid] = d.tap_dy[phase][tid];
+    s_tap[SDM_MAX_TAPS + tid] = d.tap_dx[phase][tid];
+    s_tap[2 * SDM_MAX_TAPS + tid] = d.tap_w[phase][tid];
+  }
+
+  int a_ys[AIT], a_xs[AIT];
+  long long a_base[AIT];
+#pragma unroll
+  for (int i = 0; i < AIT; ++i) {
+    int m = m0 + arow + 32 * i;
+    if (m < d.M) {
+      int n = m / HtWt, rem = m - n * HtWt;
+      int y = rem / d.Wt, x = rem - y * d.Wt;
+      a_ys[i] = y * d.sstride;
+      a_xs[i] = x * d.sstride;
+      a_base[i] = ((long long)n * d.a.H + a_ys[i]) * d.a.W + a_xs[i];
+    } else {
+      a_ys[i] = -(1 << 20); a_xs[i] = 0; a_base[i] = 0;
+    }
+  }
+  __syncthreads();   // s_orow / s_tap visible
+
+  const int ntap = d.ntaps[phase];
+  const int kch = L.kchunks;
+  const int T = ntap * kch;
+  const int it0 = (int)((long long)T * ks / L.splitk), it1 = (int)((long long)T * (ks + 1) / L.splitk);
+
+  const float* pa0[AIT];
+  const float* pa1[AIT];
+  bool aok[AIT];
+  const float* pb[BIT];
+  bool bok[BIT];
+  auto setup_tap = [&](int tp) {
+    const int dy = s_tap[tp], dx = s_tap[SDM_MAX_TAPS + tp];
+    const float* bt = bw + (long long)s_tap[2 * SDM_MAX_TAPS + tp] * d.b_tap_stride;
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+      const int sy = a_ys[i] + dy, sx = a_xs[i] + dx;
+      aok[i] = (unsigned)sy < (unsigned)d.a.H && (unsigned)sx < (unsigned)d.a.W;
+      const long long row = a_base[i] + dy * d.a.W + dx;
+      pa0[i] = a0 + row * d.a.ld0 + cc4;
+      pa1[i] = a1 + row * d.a.ld1 + (cc4 - csplit);
+    }
+    if (!BKM) {
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) {
+        const int n = n0 + arow + 32 * i;
+        bok[i] = n < N;
+        pb[i] = bt + (long long)n * d.ldb + cc4;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) {
+        const int n = n0 + 4 * (tid % CPR);
+        bok[i] = n < N;
+        pb[i] = bt + (long long)(tid / CPR + RPP * i) * d.ldb + n;
+      }
+    }
+  };
+
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  // issue the DMA of one K-step (tap state already set) into ring slot `buf`
+  auto issue = [&](int c0, int buf) {
+    const int c = c0 + cc4;
+    float* Ad = As + buf * A_TILE + __builtin_amdgcn_readfirstlane(wave) * 256;
+    float* Bd = Bs + buf * B_TILE + __builtin_amdgcn_readfirstlane(wave) * 256;
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+      const bool use = aok[i] && c < K;
+      const float* p = (c < csplit ? pa0[i] : pa1[i]) + c0;
+      p = use ? p : zero;
+      __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Ad + i * 1024), 16, 0, 0);
+    }
+    if (!BKM) {
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) {
+        const bool use = bok[i] && c < K;
+        const float* p = use ? pb[i] + c0 : zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Bd + i * 1024), 16, 0, 0);
+      }
+    } else {
+      const long long koff = (long long)c0 * d.ldb;
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) {
+        const int kk = c0 + tid / CPR + RPP * i;
+        const bool use = bok[i] && kk < K;
+        const float* p = use ? pb[i] + koff : zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Bd + i * RPP * BN), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // issue-side K-step cursor
+  int tp = it0 / kch, kc = it0 - tp * kch;
+  int issued = it0;
+  auto issue_next = [&]() {   // issues K-step `issued` (if any) into its ring slot and advances the cursor
+    if (issued < it1) {
+      if (issued == it0) {
+        setup_tap(tp);
+      } else if (++kc == kch) {
+        kc = 0;
+        setup_tap(++tp);
+      }
+      issue(kc * BK, (issued - it0) % NBUF);
+    }
+    ++issued;
+  };
+#pragma unroll
+  for (int p = 0; p < PD; ++p) issue_next();
+
+  for (int it = it0; it < it1; ++it) {
+    const int buf = (it - it0) % NBUF;
+    // tiles issued after `it` may stay in flight; everything older must have landed
+    const int younger = (it1 - 1 - it) < (PD - 1) ? (it1 - 1 - it) : (PD - 1);
+    if (younger >= 2) wait_vmcnt<2 * G>();
+    else if (younger == 1) wait_vmcnt<G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // tile `it` visible to all waves; ring slot of tile it-1 is free again
+    issue_next();                   // K-step it+PD
+    const float* Ab = As + buf * A_TILE + (wm * TM * 32 + l31) * BK;
+    const float* Bb = BKM ? Bs + buf * B_TILE + (h * 4) * BN + wn * TN * 32 + l31
+                          : Bs + buf * B_TILE + (wn * TN * 32 + l31) * BK;
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      const int ph = ((kg * 2 + h) ^ sw_l) * 4;   // swizzled chunk of this lane's fragment rows
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(Ab + i * 32 * BK + ph);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!BKM) {
+          bf[j] = *(const f32x4*)(Bb + j * 32 * BK + ph);
+        } else {
+          bf[j].x = Bb[(kg * 8 + 0) * BN + j * 32];
+          bf[j].y = Bb[(kg * 8 + 1) * BN + j * 32];
+          bf[j].z = Bb[(kg * 8 + 2) * BN + j * 32];
+          bf[j].w = Bb[(kg * 8 + 3) * BN + j * 32];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue (same contract as igemm_kernel)
+  const long long obo = b0 * d.o_bs0 + b1 * d.o_bs1;
+  const long long rbo = b0 * d.r_bs0 + b1 * d.r_bs1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + l31;
+      if (col >= N) continue;
+      const float bias = d.bias ? d.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long long orow = s_orow[row];
+        if (orow < 0) continue;
+        float v = acc[i][j][r];
+        if (L.splitk > 1) {
+          atomicAdd(&d.ws[orow * N + col], v);
+          continue;
+        }
+        v = v * d.alpha + bias;
+        if (d.out_preact) d.out_preact[obo + orow * d.ldo + col] = v;
+        v = sdm_act(v, d.act);
+        if (d.res) v += d.res[rbo + orow * d.ldres + col];
+        if (d.res2) v += d.res2[orow * d.ldres2 + col];
+        if (d.dact_z && (d.dact_ncols == 0 || col < d.dact_ncols)) v *= sdm_dsilu(d.dact_z[orow * d.ldz + col]);
+        d.out[obo + orow * d.ldo + col] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool BKM, int NBUF>
+static int launch_igemm_glds(const IgemmLaunch& L, int ntm, hipStream_t st) {
+  constexpr size_t lds = (size_t)NBUF * (BM + BN) * BK * sizeof(float) + BM * sizeof(long long) + 3 * SDM_MAX_TAPS * sizeof(int);
+  static bool attr_set = false;
+  auto kern = igemm_glds_kernel<BM, BN, WM, WN, BKM, NBUF>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(ntm * L.ntn, L.d.nphase * L.splitk, L.d.batch);
+  double taps = 0;
+  for (int p = 0; p < L.d.nphase; ++p) taps += L.d.ntaps[p];
+  sdm_prof_pre(st);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, L);
+  sdm_prof_post(st, BM == 128 ? (BN == 128 ? 0 : 5) : (BM == 64 ? 1 : 2), 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
+  SDM_CHECK_LAUNCH("igemm_glds");
+  return SDM_OK;
+}
+
 // Finishes a split-K contraction: ws holds raw sums indexed [out row][N].
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const sdm_igemm_desc d, long long rows) {
   const long long total = rows * d.N;
@@ -448,6 +718,12 @@ extern "C" size_t sdm_igemm_workspace_bytes(const sdm_igemm_desc* d) {
 
 template <int BM, int BN, int WM, int WN>
 static int dispatch_igemm(const IgemmLaunch& L, int ntm, bool kmajor, bool vec, bool aff, hipStream_t st) {
+  static const char* noglds = getenv("SDM_IGEMM_GLDS");
+  if (vec && !aff && !(noglds && noglds[0] == '0')) {
+    constexpr int NBUF = (BM * BN >= 128 * 128) ? 2 : 3;
+    return kmajor ? launch_igemm_glds<BM, BN, WM, WN, true, NBUF>(L, ntm, st)
+                  : launch_igemm_glds<BM, BN, WM, WN, false, NBUF>(L, ntm, st);
+  }
   // the affine-on-load variant exists only for K-contiguous weights (forward convs); other combinations never carry it
   if (aff) {
     if (kmajor) return sdm_set_error(SDM_ERR_UNSUPPORTED, "igemm: affine-on-load with K-major weights");
