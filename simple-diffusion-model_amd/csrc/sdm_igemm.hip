@@ -671,9 +671,15 @@ static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* w
   for (int p = 0; p < d->nphase; ++p) maxtaps = d->ntaps[p] > maxtaps ? d->ntaps[p] : maxtaps;
   const int T = maxtaps * cdiv(d->K, BK);
   const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
+  // Calibrated on MI355X (profiles/r01_igemm_tile_sweep.txt): a CU retires roughly one workgroup K-step per
+  // (matrix cycles + staging/issue overhead) whatever the co-residency (co-resident workgroups overlap ~8 %),
+  // so big tiles win whenever the grid still covers the 256 CUs evenly.
   static const double kMfma[4] = {4096, 1024, 1024, 2048};
+  static const double kOvh[4] = {3000, 900, 900, 1850};   // 128-row tiles charged +600: they co-run worse with the
+                                                           // weight-gradient stream (A/B on the training step)
   static const int kOcc[4] = {2, 4, 3, 2};
-  const double ovh = 900.0;
+  static const char* pen_s = getenv("SDM_IGEMM_BIGTILE_PENALTY");   // tuning aid: extra cycles charged to 128-row tiles
+  const double pen = pen_s ? atof(pen_s) : 0.0;
   double best = 1e300;
   int bc = 1, bs = 1;
   for (int c = 0; c < 4; ++c) {
@@ -685,12 +691,10 @@ static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* w
     for (int sk = 1; sk <= 64; sk *= 2) {
       if (sk > 1 && (d->batch != 1 || sk > T / 8)) break;
       const long nb = tiles * sk;
-      long b = (nb + 255) / 256;
-      if (b > kOcc[c]) b = kOcc[c];
-      const long rounds = (nb + 256 * b - 1) / (256 * b);
-      const double per_step = kMfma[c] * b > kMfma[c] + ovh ? kMfma[c] * b : kMfma[c] + ovh;
-      double t = (double)rounds * ((double)T / sk) * per_step + 3000.0;
-      if (sk > 1) t += 4000.0 + (double)out_rows * N * 4.0 * (sk + 2) / 256.0 / 2.0;  // atomics + finishing pass
+      const long per_cu = (nb + 255) / 256;
+      const double overlap = (per_cu >= 2 && kOcc[c] >= 2) ? 0.92 : 1.0;
+      double t = (double)per_cu * ((double)T / sk) * (kMfma[c] + kOvh[c] + ((c == 0 || c == 3) ? pen : 0.0)) * overlap + 3000.0;
+      if (sk > 1) t += 6000.0 + (double)out_rows * N * 4.0 * sk / 256.0 / 4.0;   // atomics + finishing launch
       if (t < best) { best = t; bc = c; bs = sk; }
     }
   }
