@@ -82,11 +82,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(1, torch.cuda.device_count())     # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SDM_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from models.U_Net import U_Net
     import degraders
@@ -156,9 +161,10 @@ def main():
         sample_rate = args.sample_steps / (time.perf_counter() - ts)     # includes one capture; amortised over T
         print(f"[bench] sampling: {sample_rate:.1f} steps/s", file=sys.stderr, flush=True)
 
+    if world > 1:
+        dist.barrier()                      # rank 0 may still have been sampling
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     dom = max(prof, key=lambda k: prof[k]["ms"])
