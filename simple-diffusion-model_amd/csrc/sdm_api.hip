@@ -42,9 +42,10 @@ extern "C" size_t sdm_struct_size(int which) {
 }
 
 // ---- per-launch event timing ----------------------------------------------------------------
+#include <stdlib.h>
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops; int M, N, K, taps, splitk; };
 std::vector<ProfRec> g_prof;
 int g_prof_cap = 0;
 bool g_prof_armed = false;
@@ -57,6 +58,8 @@ void sdm_prof_pre(hipStream_t st) {
   if (hipEventCreate(&g_pending) != hipSuccess) { g_pending = nullptr; return; }
   (void)hipEventRecord(g_pending, st);
 }
+static int g_pM, g_pN, g_pK, g_pT, g_pS;
+void sdm_prof_shape(int M, int N, int K, int taps, int splitk) { g_pM = M; g_pN = N; g_pK = K; g_pT = taps; g_pS = splitk; }
 void sdm_prof_post(hipStream_t st, int cls, double flops) {
   if (!g_pending) return;
   ProfRec r;
@@ -66,6 +69,7 @@ void sdm_prof_post(hipStream_t st, int cls, double flops) {
   (void)hipEventRecord(r.b, st);
   r.cls = cls;
   r.flops = flops;
+  r.M = g_pM; r.N = g_pN; r.K = g_pK; r.taps = g_pT; r.splitk = g_pS;
   g_prof.push_back(r);
 }
 
@@ -83,6 +87,9 @@ extern "C" int sdm_prof_end(double* ms, long long* launches, double* flops) {
   SDM_CHECK_ARG(ms && launches && flops, "prof_end: null");
   g_prof_armed = false;
   for (int c = 0; c < SDM_PROF_CLASSES; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; }
+  const char* dump = getenv("SDM_PROF_DUMP");     // optional per-launch CSV (tuning aid)
+  FILE* df = dump ? fopen(dump, "w") : nullptr;
+  if (df) fprintf(df, "cls,M,N,K,taps,splitk,us,tflops\n");
   for (auto& r : g_prof) {
     if (hipEventSynchronize(r.b) != hipSuccess) return sdm_set_error(SDM_ERR_LAUNCH, "prof_end: event sync failed");
     float t = 0.f;
@@ -90,10 +97,12 @@ extern "C" int sdm_prof_end(double* ms, long long* launches, double* flops) {
       ms[r.cls] += t;
       launches[r.cls] += 1;
       flops[r.cls] += r.flops;
+      if (df) fprintf(df, "%d,%d,%d,%d,%d,%d,%.1f,%.1f\n", r.cls, r.M, r.N, r.K, r.taps, r.splitk, t * 1e3, r.flops / (t * 1e-3) / 1e12);
     }
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
   }
+  if (df) fclose(df);
   g_prof.clear();
   return SDM_OK;
 }

@@ -593,6 +593,7 @@ static int launch_igemm_glds(const IgemmLaunch& L, int ntm, hipStream_t st) {
   dim3 grid(ntm * L.ntn, L.d.nphase * L.splitk, L.d.batch);
   double taps = 0;
   for (int p = 0; p < L.d.nphase; ++p) taps += L.d.ntaps[p];
+  sdm_prof_shape(L.d.M, L.d.N, L.d.K, (int)taps, L.splitk);
   sdm_prof_pre(st);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, L);
   sdm_prof_post(st, BM == 128 ? (BN == 128 ? 0 : 5) : (BM == 64 ? 1 : 2), 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
@@ -629,6 +630,7 @@ static int launch_igemm(const IgemmLaunch& L, int ntm, hipStream_t st) {
   dim3 grid(ntm * L.ntn, L.d.nphase * L.splitk, L.d.batch);
   double taps = 0;
   for (int p = 0; p < L.d.nphase; ++p) taps += L.d.ntaps[p];
+  sdm_prof_shape(L.d.M, L.d.N, L.d.K, (int)taps, L.splitk);
   sdm_prof_pre(st);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, L);
   sdm_prof_post(st, BM == 128 ? (BN == 128 ? 0 : 5) : (BM == 64 ? 1 : 2), 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
@@ -982,6 +984,7 @@ static int launch_wgrad(const WgradLaunch& L, int ntm, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<BT, WM, WN, VEC, AFF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  sdm_prof_shape(L.d.M, L.d.N, (int)((long)L.d.images * L.d.Hk * L.d.Wk), L.d.ntaps, L.splitk);
   sdm_prof_pre(st);
   hipLaunchKernelGGL((wgrad_kernel<BT, WM, WN, VEC, AFF>), grid, dim3(256), lds, st, L);
   sdm_prof_post(st, BT == 128 ? 3 : 4,
