@@ -167,6 +167,14 @@ def main():
         dist.destroy_process_group()
         return
 
+    # HBM bytes per launch of each class from the committed rocprofv3 PMC passes of this same command
+    # (profiles/r01_hbm_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None when the file is absent
+    traffic = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            traffic = {k: v["total"] for k, v in json.load(f)["per_class_hbm_bytes_per_launch"].items()}
+    except Exception:
+        pass
     dom = max(prof, key=lambda k: prof[k]["ms"])
     d = prof[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
@@ -192,7 +200,10 @@ def main():
         "sample_config": None if sample_rate is None else "DDPM hipGraph step, batch %d, %d steps timed incl. capture"
                                                           % (args.batch, args.sample_steps),
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get(dom),
+                     "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
+                                       "bytes per launch)" if dom in traffic else None,
+                     "algorithmic_bytes_per_launch": (4.0 * d["bytes"] / max(1, d["launches"])) if "bytes" in d else None,
                      "launches": d["launches"], "avg_launch_ms": d["ms"] / max(1, d["launches"]),
                      "measured_over": "%d steps (%.2f ms/step) with HIP event pairs around every contraction launch, run right "
                                       "after the timed region with the weight-gradient side stream off so that each launch "
