@@ -203,7 +203,8 @@ def main():
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get(dom),
                      "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
                                        "bytes per launch)" if dom in traffic else None,
-                     "algorithmic_bytes_per_launch": (4.0 * d["bytes"] / max(1, d["launches"])) if "bytes" in d else None,
+                     "algorithmic_bytes_per_launch": d["bytes"] / max(1, d["launches"]),
+                     "hbm_GBps_algorithmic": d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0,
                      "launches": d["launches"], "avg_launch_ms": d["ms"] / max(1, d["launches"]),
                      "measured_over": "%d steps (%.2f ms/step) with HIP event pairs around every contraction launch, run right "
                                       "after the timed region with the weight-gradient side stream off so that each launch "

@@ -45,7 +45,7 @@ extern "C" size_t sdm_struct_size(int which) {
 #include <stdlib.h>
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; int cls; double flops; int M, N, K, taps, splitk; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; int M, N, K, taps, splitk; };
 std::vector<ProfRec> g_prof;
 int g_prof_cap = 0;
 bool g_prof_armed = false;
@@ -59,7 +59,10 @@ void sdm_prof_pre(hipStream_t st) {
   (void)hipEventRecord(g_pending, st);
 }
 static int g_pM, g_pN, g_pK, g_pT, g_pS;
-void sdm_prof_shape(int M, int N, int K, int taps, int splitk) { g_pM = M; g_pN = N; g_pK = K; g_pT = taps; g_pS = splitk; }
+static double g_pB;
+void sdm_prof_shape(int M, int N, int K, int taps, int splitk, double bytes) {
+  g_pM = M; g_pN = N; g_pK = K; g_pT = taps; g_pS = splitk; g_pB = bytes;
+}
 void sdm_prof_post(hipStream_t st, int cls, double flops) {
   if (!g_pending) return;
   ProfRec r;
@@ -69,6 +72,7 @@ void sdm_prof_post(hipStream_t st, int cls, double flops) {
   (void)hipEventRecord(r.b, st);
   r.cls = cls;
   r.flops = flops;
+  r.bytes = g_pB;
   r.M = g_pM; r.N = g_pN; r.K = g_pK; r.taps = g_pT; r.splitk = g_pS;
   g_prof.push_back(r);
 }
@@ -83,10 +87,10 @@ extern "C" int sdm_prof_begin(int capacity) {
   return SDM_OK;
 }
 
-extern "C" int sdm_prof_end(double* ms, long long* launches, double* flops) {
-  SDM_CHECK_ARG(ms && launches && flops, "prof_end: null");
+extern "C" int sdm_prof_end(double* ms, long long* launches, double* flops, double* bytes) {
+  SDM_CHECK_ARG(ms && launches && flops && bytes, "prof_end: null");
   g_prof_armed = false;
-  for (int c = 0; c < SDM_PROF_CLASSES; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; }
+  for (int c = 0; c < SDM_PROF_CLASSES; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; bytes[c] = 0; }
   const char* dump = getenv("SDM_PROF_DUMP");     // optional per-launch CSV (tuning aid)
   FILE* df = dump ? fopen(dump, "w") : nullptr;
   if (df) fprintf(df, "cls,M,N,K,taps,splitk,us,tflops\n");
@@ -97,6 +101,7 @@ extern "C" int sdm_prof_end(double* ms, long long* launches, double* flops) {
       ms[r.cls] += t;
       launches[r.cls] += 1;
       flops[r.cls] += r.flops;
+      bytes[r.cls] += r.bytes;
       if (df) fprintf(df, "%d,%d,%d,%d,%d,%d,%.1f,%.1f\n", r.cls, r.M, r.N, r.K, r.taps, r.splitk, t * 1e3, r.flops / (t * 1e-3) / 1e12);
     }
     (void)hipEventDestroy(r.a);

@@ -64,4 +64,4 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 bool sdm_prof_on();
 void sdm_prof_pre(hipStream_t st);
 void sdm_prof_post(hipStream_t st, int cls, double flops);
-void sdm_prof_shape(int M, int N, int K, int taps, int splitk);
+void sdm_prof_shape(int M, int N, int K, int taps, int splitk, double bytes);

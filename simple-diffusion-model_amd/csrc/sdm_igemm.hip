@@ -593,7 +593,11 @@ static int launch_igemm_glds(const IgemmLaunch& L, int ntm, hipStream_t st) {
   dim3 grid(ntm * L.ntn, L.d.nphase * L.splitk, L.d.batch);
   double taps = 0;
   for (int p = 0; p < L.d.nphase; ++p) taps += L.d.ntaps[p];
-  sdm_prof_shape(L.d.M, L.d.N, L.d.K, (int)taps, L.splitk);
+  {  // algorithmic bytes: every input row, weight and output element once (SURVEY 8d rule)
+    const double images = (double)L.d.M / ((double)L.d.Ht * L.d.Wt);
+    const double in_b = images * L.d.a.H * L.d.a.W * L.d.K, w_b = (double)L.d.K * L.d.N * taps, out_b = images * L.d.Ho * L.d.Wo * L.d.N;
+    sdm_prof_shape(L.d.M, L.d.N, L.d.K, (int)taps, L.splitk, 4.0 * L.d.batch * (in_b + w_b + out_b));
+  }
   sdm_prof_pre(st);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, L);
   sdm_prof_post(st, BM == 128 ? (BN == 128 ? 0 : 5) : (BM == 64 ? 1 : 2), 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
@@ -630,7 +634,11 @@ static int launch_igemm(const IgemmLaunch& L, int ntm, hipStream_t st) {
   dim3 grid(ntm * L.ntn, L.d.nphase * L.splitk, L.d.batch);
   double taps = 0;
   for (int p = 0; p < L.d.nphase; ++p) taps += L.d.ntaps[p];
-  sdm_prof_shape(L.d.M, L.d.N, L.d.K, (int)taps, L.splitk);
+  {  // algorithmic bytes: every input row, weight and output element once (SURVEY 8d rule)
+    const double images = (double)L.d.M / ((double)L.d.Ht * L.d.Wt);
+    const double in_b = images * L.d.a.H * L.d.a.W * L.d.K, w_b = (double)L.d.K * L.d.N * taps, out_b = images * L.d.Ho * L.d.Wo * L.d.N;
+    sdm_prof_shape(L.d.M, L.d.N, L.d.K, (int)taps, L.splitk, 4.0 * L.d.batch * (in_b + w_b + out_b));
+  }
   sdm_prof_pre(st);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, L);
   sdm_prof_post(st, BM == 128 ? (BN == 128 ? 0 : 5) : (BM == 64 ? 1 : 2), 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
@@ -984,7 +992,11 @@ static int launch_wgrad(const WgradLaunch& L, int ntm, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<BT, WM, WN, VEC, AFF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  sdm_prof_shape(L.d.M, L.d.N, (int)((long)L.d.images * L.d.Hk * L.d.Wk), L.d.ntaps, L.splitk);
+  {
+    const double px = (double)L.d.images;
+    const double g_b = px * L.d.g.H * L.d.g.W * L.d.M, x_b = px * L.d.x.H * L.d.x.W * L.d.N, w_b = (double)L.d.M * L.d.N * L.d.ntaps;
+    sdm_prof_shape(L.d.M, L.d.N, (int)((long)L.d.images * L.d.Hk * L.d.Wk), L.d.ntaps, L.splitk, 4.0 * L.d.batch * (g_b + x_b + w_b));
+  }
   sdm_prof_pre(st);
   hipLaunchKernelGGL((wgrad_kernel<BT, WM, WN, VEC, AFF>), grid, dim3(256), lds, st, L);
   sdm_prof_post(st, BT == 128 ? 3 : 4,

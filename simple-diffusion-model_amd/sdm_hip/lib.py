@@ -83,7 +83,7 @@ _PROTOS = {
     "sdm_device_info": (C.c_int, [C.POINTER(C.c_int)]),
     "sdm_struct_size": (_sz, [_i]),
     "sdm_prof_begin": (_i, [_i]),
-    "sdm_prof_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    "sdm_prof_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sdm_igemm": (_i, [C.POINTER(IgemmDesc), fp]),
     "sdm_igemm_workspace_bytes": (_sz, [C.POINTER(IgemmDesc)]),
     "sdm_wgrad": (_i, [C.POINTER(WgradDesc), fp]),
@@ -159,5 +159,6 @@ def prof_end():
     ms = (C.c_double * 6)()
     n = (C.c_longlong * 6)()
     fl = (C.c_double * 6)()
-    call("sdm_prof_end", ms, n, fl)
-    return {PROF_CLASSES[i]: dict(ms=ms[i], launches=n[i], flops=fl[i]) for i in range(6)}
+    by = (C.c_double * 6)()
+    call("sdm_prof_end", ms, n, fl, by)
+    return {PROF_CLASSES[i]: dict(ms=ms[i], launches=n[i], flops=fl[i], bytes=by[i]) for i in range(6)}
