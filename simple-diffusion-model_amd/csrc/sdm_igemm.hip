@@ -1024,8 +1024,10 @@ extern "C" int sdm_wgrad(const sdm_wgrad_desc* d, sdm_stream_t stream) {
   L.d = *d;
   const long P = (long)d->images * d->Hk * d->Wk;
   const int T = cdiv(P, BK);
-  // 128x128 tiles only when they alone keep the chip busy; otherwise 64x64 tiles (4x the workgroups per split)
-  const bool big = d->M >= 128 && d->N >= 128 && (long)cdiv(d->M, 128) * cdiv(d->N, 128) * d->ntaps * d->batch >= 256;
+  // 128x128 tiles when they keep the chip busy on their own, or when split-K over pixels can supply the parallelism
+  // while each workgroup still walks >= 32 K-steps (amortises its 64 KB atomic epilogue); else 64x64 tiles
+  const long blocks128 = (long)cdiv(d->M, 128) * cdiv(d->N, 128) * d->ntaps * d->batch;
+  const bool big = d->M >= 128 && d->N >= 128 && (blocks128 >= 256 || (long)T * blocks128 >= 32L * 512);
   const int bt = big ? 128 : 64;
   const int ntm = cdiv(d->M, bt);
   L.ntn = cdiv(d->N, bt);
