@@ -975,6 +975,177 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
     }
 }
 
+// LDS-DMA variant of the weight-gradient kernel (aligned operands, no pending affine on x): both pixel-row tiles
+// go global -> LDS with global_load_lds_dwordx4 into a ring of NBUF slots (lane-linear [k][channel] images, read
+// down the columns, so no swizzle is needed); out-of-image taps read the zero word.
+template <int BT, int WM, int WN, int NBUF>
+__global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradLaunch L) {
+  const sdm_wgrad_desc& d = L.d;
+  constexpr int TM = BT / (WM * 32), TN = BT / (WN * 32);
+  constexpr int IT = BT / 32;
+  constexpr int TILE = BK * BT;
+  constexpr int CPR = BT / 4, RPP = 256 / CPR;
+  constexpr int G = 2 * IT;
+  constexpr int PD = NBUF - 1;
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;
+  float* Bs = smem + NBUF * TILE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
+  const int tile_n = blockIdx.x % L.ntn, tile_m = blockIdx.x / L.ntn;
+  const int tp = blockIdx.y / L.splitk, ks = blockIdx.y % L.splitk;
+  const int m0 = tile_m * BT, n0 = tile_n * BT;
+  const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
+  const float* g0 = d.g.p0 + b0 * d.g_bs0 + b1 * d.g_bs1;
+  const float* x0 = d.x.p0 + b0 * d.x_bs0 + b1 * d.x_bs1;
+  const float* x1 = d.x.p1;
+  const float* zero = g_zero_chunk;
+  const int HW = d.Hk * d.Wk;
+  const long long P = (long long)d.images * HW;
+  const int T = (int)((P + BK - 1) / BK);
+  const int it0 = (int)((long long)T * ks / L.splitk), it1 = (int)((long long)T * (ks + 1) / L.splitk);
+  const int gdy = d.g_dy[tp], gdx = d.g_dx[tp], xdy = d.x_dy[tp], xdx = d.x_dx[tp];
+  const int cm = m0 + 4 * (tid % CPR), cn = n0 + 4 * (tid % CPR);
+  const bool gch = cm < d.M, xch = cn < d.N;
+  const bool xsrc0 = cn < d.x.csplit;
+  const bool do_bias = d.dbias != nullptr && tile_n == 0 && tp == 0;   // block-uniform
+  float bacc = 0.f;
+
+  int pn[IT], py[IT], px[IT];
+  const int adv_x = BK % d.Wk, q32 = BK / d.Wk;
+  const int adv_y = q32 % d.Hk, adv_n = q32 / d.Hk;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const long long p = (long long)it0 * BK + tid / CPR + RPP * i;
+    const int n = (int)(p / HW), rem = (int)(p - (long long)n * HW);
+    pn[i] = n;
+    py[i] = rem / d.Wk;
+    px[i] = rem - py[i] * d.Wk;
+  }
+
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  int issued = it0;
+  auto issue_next = [&]() {
+    if (issued < it1) {
+      const int buf = (issued - it0) % NBUF;
+      float* Ad = As + buf * TILE + __builtin_amdgcn_readfirstlane(wave) * 256;
+      float* Bd = Bs + buf * TILE + __builtin_amdgcn_readfirstlane(wave) * 256;
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int n = pn[i], y = py[i], x = px[i];
+        const bool in = n < d.images;
+        const int gy = y * d.g_stride + gdy, gx = x * d.g_stride + gdx;
+        const int xy = y * d.x_stride + xdy, xx = x * d.x_stride + xdx;
+        const bool gu = in && gch && (unsigned)gy < (unsigned)d.g.H && (unsigned)gx < (unsigned)d.g.W;
+        const bool xu = in && xch && (unsigned)xy < (unsigned)d.x.H && (unsigned)xx < (unsigned)d.x.W;
+        const long long xrow = ((long long)n * d.x.H + xy) * d.x.W + xx;
+        const float* gq = g0 + (((long long)n * d.g.H + gy) * d.g.W + gx) * d.g.ld0 + cm;
+        const float* xq = xsrc0 ? x0 + xrow * d.x.ld0 + cn : x1 + xrow * d.x.ld1 + (cn - d.x.csplit);
+        gq = gu ? gq : zero;
+        xq = xu ? xq : zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr)gq, (lds_ptr)(Ad + i * RPP * BT), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)xq, (lds_ptr)(Bd + i * RPP * BT), 16, 0, 0);
+        int nx = x + adv_x, ny = y + adv_y, nn = n + adv_n;
+        if (nx >= d.Wk) { nx -= d.Wk; ny += 1; }
+        if (ny >= d.Hk) { ny -= d.Hk; nn += 1; }
+        px[i] = nx; py[i] = ny; pn[i] = nn;
+      }
+    }
+    ++issued;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int p = 0; p < PD; ++p) issue_next();
+  for (int it = it0; it < it1; ++it) {
+    const int buf = (it - it0) % NBUF;
+    const int younger = (it1 - 1 - it) < (PD - 1) ? (it1 - 1 - it) : (PD - 1);
+    if (younger >= 2) wait_vmcnt<2 * G>();
+    else if (younger == 1) wait_vmcnt<G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    issue_next();
+    const float* Ab = As + buf * TILE + (h * 4) * BT + wm * TM * 32 + l31;
+    const float* Bb = Bs + buf * TILE + (h * 4) * BT + wn * TN * 32 + l31;
+    if (do_bias && tid < BT) {   // column sums of the gradient tile (bias gradient)
+      const float* col = As + buf * TILE + tid;
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < BK; ++k) a += col[k * BT];
+      bacc += a;
+    }
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      float af[TM][4], bf[TN][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i][s] = Ab[(kg * 8 + s) * BT + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j][s] = Bb[(kg * 8 + s) * BT + j * 32];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+  }
+  if (do_bias && tid < BT && m0 + tid < d.M) atomicAdd(&d.dbias[m0 + tid], bacc);
+
+  float* dw = d.dw + b0 * d.w_bs0 + b1 * d.w_bs1 + (long long)d.tap_w[tp] * d.w_tap_stride;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + l31;
+      if (col >= d.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= d.M) continue;
+        float* q = dw + (long long)row * d.ldw + col;
+        const float v = acc[i][j][r] * d.alpha;
+        if (L.atomic_out) atomicAdd(q, v);
+        else *q = v;
+      }
+    }
+}
+
+template <int BT, int WM, int WN, int NBUF>
+static int launch_wgrad_glds(const WgradLaunch& L, int ntm, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * NBUF * BK * BT * sizeof(float);
+  dim3 grid(ntm * L.ntn, L.d.ntaps * L.splitk, L.d.batch);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)wgrad_glds_kernel<BT, WM, WN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_set = true;
+  }
+  {
+    const double px = (double)L.d.images;
+    const double g_b = px * L.d.g.H * L.d.g.W * L.d.M, x_b = px * L.d.x.H * L.d.x.W * L.d.N, w_b = (double)L.d.M * L.d.N * L.d.ntaps;
+    sdm_prof_shape(L.d.M, L.d.N, (int)((long)L.d.images * L.d.Hk * L.d.Wk), L.d.ntaps, L.splitk, 4.0 * L.d.batch * (g_b + x_b + w_b));
+  }
+  sdm_prof_pre(st);
+  hipLaunchKernelGGL((wgrad_glds_kernel<BT, WM, WN, NBUF>), grid, dim3(256), lds, st, L);
+  sdm_prof_post(st, BT == 128 ? 3 : 4,
+                2.0 * L.d.M * L.d.N * (double)L.d.images * L.d.Hk * L.d.Wk * L.d.ntaps * L.d.batch);
+  SDM_CHECK_LAUNCH("wgrad_glds");
+  return SDM_OK;
+}
+
 __global__ void zero_rows_kernel(float* p, long long rows, int cols, long long ld) {
   const long long total = rows * cols;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -1065,6 +1236,9 @@ extern "C" int sdm_wgrad(const sdm_wgrad_desc* d, sdm_stream_t stream) {
     }
   }
   const bool aff = d->x.scale != nullptr;
+  static const char* noglds = getenv("SDM_IGEMM_GLDS");
+  if (vec && !aff && !(noglds && noglds[0] == '0'))
+    return big ? launch_wgrad_glds<128, 2, 2, 2>(L, ntm, st) : launch_wgrad_glds<64, 2, 2, 3>(L, ntm, st);
   if (big) {
     if (aff) return vec ? launch_wgrad<128, 2, 2, true, true>(L, ntm, st) : launch_wgrad<128, 2, 2, false, true>(L, ntm, st);
     return vec ? launch_wgrad<128, 2, 2, true, false>(L, ntm, st) : launch_wgrad<128, 2, 2, false, false>(L, ntm, st);
