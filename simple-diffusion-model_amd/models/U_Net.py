@@ -137,10 +137,11 @@ class U_Net(nn.Module):
                 raise RuntimeError("training needs one timestep per image (t of shape [N])")
             ctx.emb = emb
             if self._adagns:             # all y_scale projections of the net in one launch
-                views = self._bank.forward([a.y_scale for a in self._adagns], emb)
+                views = self._bank.forward([a.y_scale for a in self._adagns], emb, private=ctx.train)
                 ctx.mods = dict(zip(self._adagns, views))
                 if ctx.train:
-                    ctx.dmods = dict(zip(self._adagns, self._bank.dviews))
+                    ctx.bank = self._bank.tables()
+                    ctx.dmods = dict(zip(self._adagns, ctx.bank["dviews"]))
         stem = self.in_layer[0].conv_layer.conv
         a = ops.stem_conv(x, stem.taps(), stem.bias, ACT_SILU, save_z=ctx.train)
         if ctx.train:
@@ -225,7 +226,7 @@ class U_Net(nn.Module):
         hook("in_layer")
         if self.cond_emb is not None:
             if ctx.dmods is not None:
-                self._bank.backward_dx(ctx.demb)
+                self._bank.backward_dx(ctx.bank, ctx.demb)
             self.cond_emb.backward(ctx, ctx.demb, grads)
             hook("cond_emb")
         ops.SIDE.join()

@@ -46,6 +46,7 @@ class RunCtx:
         self.demb = None
         self.mods = None      # {AdaGN: modulation rows} when the net evaluated all y_scale projections in one launch
         self.dmods = None     # {AdaGN: gradient rows} consumed by the batched y_scale data gradient
+        self.bank = None      # the y_scale job tables this forward used (ops.LinearBank.tables())
 
 
 def to_rows(x_nchw):

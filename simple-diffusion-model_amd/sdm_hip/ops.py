@@ -633,7 +633,7 @@ class LinearBank:
         self.chunk_o0 = torch.tensor(co, dtype=torch.int32, device=dev)
         self.maxO = max(self.sizes)
 
-    def forward(self, linears, emb):
+    def forward(self, linears, emb, private=False):
         M, K = emb.shape
         key = (M, emb.device, tuple(l.weight.data_ptr() for l in linears), tuple(l.bias.data_ptr() for l in linears))
         if key != self.key:
@@ -648,10 +648,24 @@ class LinearBank:
                     setattr(self, k, v)
             self.key = key
         lib.call("sdm_linear_multi", _p(emb), emb.stride(0), M, K, _p(self.jobs), len(linears), self.maxO, _stream())
-        return self.views
+        if not private:
+            return self.views
+        # training: the modulation rows are read again by backward, possibly after another forward has reused the
+        # bank's output buffer -> hand out views of a private copy (one device-to-device copy)
+        flat, views, off = self.out.clone(), [], 0
+        for O in self.sizes:
+            views.append(flat[off:off + M * O].view(M, O))
+            off += M * O
+        return views
 
-    def backward_dx(self, demb):
-        """demb[m][k] += sum over all projections of dmod_j @ W_j (dmod_j were written into self.dviews)."""
+    def tables(self):
+        """The table set of the most recent forward (keep it with the forward's context: a later forward with another
+        embedding batch switches the bank to a different set)."""
+        return self.built[self.key]
+
+    @staticmethod
+    def backward_dx(tables, demb):
+        """demb[m][k] += sum over all projections of dmod_j @ W_j (dmod_j were written into tables['dviews'])."""
         M, K = demb.shape
-        lib.call("sdm_linear_multi_bwd_dx", _p(self.bjobs), _p(self.chunk_job), _p(self.chunk_o0), self.chunk_job.numel(),
-                 _p(demb), demb.stride(0), M, K, _stream())
+        lib.call("sdm_linear_multi_bwd_dx", _p(tables["bjobs"]), _p(tables["chunk_job"]), _p(tables["chunk_o0"]),
+                 tables["chunk_job"].numel(), _p(demb), demb.stride(0), M, K, _stream())

@@ -559,3 +559,32 @@ def test_classifier_free_guidance_matches_two_pass_oracle(dev, O, use_graph):
     out = S.ddim_sampling(net, D.NoiseDegradation(5e-3, 9e-3, 1000, "cuda"), xT.cuda(), 1, 401, labels_tensor=labels.cuda(),
                           ddim_step_size=200, device="cuda", log=lambda *a, **k: None, use_graph=use_graph, cfg_scale=w)
     assert torch.allclose(out.cpu(), x0, rtol=1e-3, atol=1e-4), float((out.cpu() - x0).abs().max())
+
+
+def test_two_forwards_then_backward_accumulates(dev, O):
+    """Gradient accumulation through autograd: two forwards (different batches, a sampling-style batch-1 call in
+    between) followed by one backward of the summed loss must give the sum of the two oracle gradients."""
+    cfg, net = narrow_net(O)
+    P = O.seeded_params(cfg, seed=3, gain=1.8)
+    g = torch.Generator().manual_seed(8)
+    xs = [torch.randn(2, 3, 16, 16, generator=g), torch.randn(3, 3, 8, 8, generator=g)]
+    ts = [torch.tensor([5, 900]), torch.tensor([1, 400, 777])]
+    cs = [torch.eye(3)[[0, 1]], torch.eye(3)[[2, 2, 0]]]
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = sum((O.unet_forward(Pg, cfg, x, t, c) ** 2).mean() for x, t, c in zip(xs, ts, cs))
+    ref.backward()
+    net.train()
+    y0 = net(xs[0].cuda(), ts[0].cuda(), cs[0].cuda())
+    with torch.no_grad():
+        net(xs[0][:1].cuda(), ts[0][:1].cuda(), cs[0][0].cuda())          # batch-1 embedding call in between
+    y1 = net(xs[1].cuda(), ts[1].cuda(), cs[1].cuda())
+    ((y0 ** 2).mean() + (y1 ** 2).mean()).backward()
+    bad = []
+    for k, p in net.named_parameters():
+        if Pg[k].grad is None:
+            continue
+        e = rel(p.grad, Pg[k].grad)
+        lim = 2e-3 if (".conv_block_" in k and k.endswith("conv_layer.0.bias")) else 2e-4
+        if e > lim:
+            bad.append((k, e))
+    assert not bad, bad[:8]
