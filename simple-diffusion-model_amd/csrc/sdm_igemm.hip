@@ -19,7 +19,17 @@
 struct IgemmLaunch {
   sdm_igemm_desc d;
   int splitk, ntn, kchunks;
+  int mfast;   // tile order inside one XCD's run: 0 = N-tiles fastest (A rows shared in L2), 1 = M-tiles fastest (B shared)
 };
+
+// Workgroups go to the 8 XCDs round-robin by linear id and every XCD has its own L2.  Remap blockIdx.x so that one
+// XCD owns a contiguous run of the tile order: tiles that share an operand then meet in one L2 instead of each
+// XCD fetching its own copy from HBM.  (Bijective for any grid size; the grid's y/z dimensions -- taps, split-K
+// slices, images -- keep their XCD when gridDim.x is a multiple of 8, which the planner's tile counts mostly are.)
+__device__ __forceinline__ int xcd_contiguous(int bid, int total) {
+  const int q = total >> 3, r = total & 7, x = bid & 7, i = bid >> 3;
+  return x < r ? x * (q + 1) + i : r * (q + 1) + (x - r) * q + i;
+}
 
 // One K-step = (tap, 32-channel chunk).  Per-tap state (row pointers, validity) is rebuilt only when the tap
 // changes; inside a tap the loads are pointer + running channel offset, so the steady-state loop is
@@ -40,7 +50,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
-  const int tile_n = blockIdx.x % L.ntn, tile_m = blockIdx.x / L.ntn;
+  const int tile_id = L.mfast == 2 ? (int)blockIdx.x : xcd_contiguous(blockIdx.x, gridDim.x), ntm_ = gridDim.x / L.ntn;
+  const int tile_n = L.mfast == 1 ? tile_id / ntm_ : tile_id % L.ntn, tile_m = L.mfast == 1 ? tile_id % ntm_ : tile_id / L.ntn;
   const int phase = blockIdx.y / L.splitk, ks = blockIdx.y % L.splitk;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
@@ -346,14 +357,17 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, bool BKM, int NBUF>
+template <int BM, int BN, int WM, int WN, bool BKM, int NBUF, int BKT>
 __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
   const sdm_igemm_desc& d = L.d;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int AIT = BM / 32, BIT = BN / 32;
-  constexpr int A_TILE = BM * BK;
-  constexpr int B_TILE = BN * BK;
-  constexpr int CPR = BN / 4, RPP = 256 / CPR;
+  constexpr int CA = BKT / 4;                     // 16-byte chunks per K-contiguous tile row
+  constexpr int RA = 256 / CA;                    // tile rows covered by one pass of the 256 threads
+  constexpr int AIT = BM / RA;                    // passes for the A tile
+  constexpr int CPR = BN / 4, RPP = 256 / CPR;    // K-major B: chunks per k-row, k-rows per pass
+  constexpr int BIT = BKM ? BKT / RPP : BN / RA;  // passes for the B tile
+  constexpr int A_TILE = BM * BKT;
+  constexpr int B_TILE = BN * BKT;
   constexpr int G = AIT + BIT;      // LDS-DMA instructions per thread per K-step
   constexpr int PD = NBUF - 1;      // prefetch distance in K-steps
   extern __shared__ __align__(16) float smem[];
@@ -364,7 +378,8 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
-  const int tile_n = blockIdx.x % L.ntn, tile_m = blockIdx.x / L.ntn;
+  const int tile_id = L.mfast == 2 ? (int)blockIdx.x : xcd_contiguous(blockIdx.x, gridDim.x), ntm_ = gridDim.x / L.ntn;
+  const int tile_n = L.mfast == 1 ? tile_id / ntm_ : tile_id % L.ntn, tile_m = L.mfast == 1 ? tile_id % ntm_ : tile_id / L.ntn;
   const int phase = blockIdx.y / L.splitk, ks = blockIdx.y % L.splitk;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
@@ -373,10 +388,11 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
   const float* bw = d.b + b0 * d.b_bs0 + b1 * d.b_bs1;
   const int HtWt = d.Ht * d.Wt;
   const int K = d.K, N = d.N, csplit = d.a.csplit;
-  const int arow = tid >> 3;
-  // logical 16-byte chunk this lane fetches for its physical slot (tid&7): slot ^ ((row>>1)&7); rows arow+32i share it
-  const int cc4 = 4 * ((tid & 7) ^ ((arow >> 1) & 7));
-  const int sw_l = (l31 >> 1) & 7;  // swizzle of the fragment rows this lane reads
+  const int arow = tid / CA;
+  // logical 16-byte chunk this lane fetches for its physical slot (tid % CA): slot ^ key(row); key = (row>>1)&7 for
+  // 128-byte rows (BKT 32), row&15 for 256-byte rows (BKT 64); rows arow + RA*i share it
+  const int cc4 = 4 * ((tid % CA) ^ (BKT == 32 ? ((arow >> 1) & 7) : (arow & 15)));
+  const int sw_l = BKT == 32 ? ((l31 >> 1) & 7) : (l31 & 15);  // swizzle key of the fragment rows this lane reads
   const float* zero = g_zero_chunk;
 
   for (int r = tid; r < BM; r += 256) {
@@ -400,7 +416,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
   long long a_base[AIT];
 #pragma unroll
   for (int i = 0; i < AIT; ++i) {
-    int m = m0 + arow + 32 * i;
+    int m = m0 + arow + RA * i;
     if (m < d.M) {
       int n = m / HtWt, rem = m - n * HtWt;
       int y = rem / d.Wt, x = rem - y * d.Wt;
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
     if (!BKM) {
 #pragma unroll
       for (int i = 0; i < BIT; ++i) {
-        const int n = n0 + arow + 32 * i;
+        const int n = n0 + arow + RA * i;
         bok[i] = n < N;
         pb[i] = bt + (long long)n * d.ldb + cc4;
       }
@@ -463,14 +479,14 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
       const bool use = aok[i] && c < K;
       const float* p = (c < csplit ? pa0[i] : pa1[i]) + c0;
       p = use ? p : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Ad + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Ad + i * RA * BKT), 16, 0, 0);
     }
     if (!BKM) {
 #pragma unroll
       for (int i = 0; i < BIT; ++i) {
         const bool use = bok[i] && c < K;
         const float* p = use ? pb[i] + c0 : zero;
-        __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Bd + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Bd + i * RA * BKT), 16, 0, 0);
       }
     } else {
       const long long koff = (long long)c0 * d.ldb;
@@ -503,7 +519,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
         kc = 0;
         setup_tap(++tp);
       }
-      issue(kc * BK, (issued - it0) % NBUF);
+      issue(kc * BKT, (issued - it0) % NBUF);
     }
     ++issued;
   };
@@ -519,19 +535,19 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // tile `it` visible to all waves; ring slot of tile it-1 is free again
     issue_next();                   // K-step it+PD
-    const float* Ab = As + buf * A_TILE + (wm * TM * 32 + l31) * BK;
+    const float* Ab = As + buf * A_TILE + (wm * TM * 32 + l31) * BKT;
     const float* Bb = BKM ? Bs + buf * B_TILE + (h * 4) * BN + wn * TN * 32 + l31
-                          : Bs + buf * B_TILE + (wn * TN * 32 + l31) * BK;
+                          : Bs + buf * B_TILE + (wn * TN * 32 + l31) * BKT;
 #pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) {
+    for (int kg = 0; kg < BKT / 8; ++kg) {
       const int ph = ((kg * 2 + h) ^ sw_l) * 4;   // swizzled chunk of this lane's fragment rows
       f32x4 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(Ab + i * 32 * BK + ph);
+      for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(Ab + i * 32 * BKT + ph);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (!BKM) {
-          bf[j] = *(const f32x4*)(Bb + j * 32 * BK + ph);
+          bf[j] = *(const f32x4*)(Bb + j * 32 * BKT + ph);
         } else {
           bf[j].x = Bb[(kg * 8 + 0) * BN + j * 32];
           bf[j].y = Bb[(kg * 8 + 1) * BN + j * 32];
@@ -581,11 +597,11 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool BKM, int NBUF>
+template <int BM, int BN, int WM, int WN, bool BKM, int NBUF, int BKT>
 static int launch_igemm_glds(const IgemmLaunch& L, int ntm, hipStream_t st) {
-  constexpr size_t lds = (size_t)NBUF * (BM + BN) * BK * sizeof(float) + BM * sizeof(long long) + 3 * SDM_MAX_TAPS * sizeof(int);
+  constexpr size_t lds = (size_t)NBUF * (BM + BN) * BKT * sizeof(float) + BM * sizeof(long long) + 3 * SDM_MAX_TAPS * sizeof(int);
   static bool attr_set = false;
-  auto kern = igemm_glds_kernel<BM, BN, WM, WN, BKM, NBUF>;
+  auto kern = igemm_glds_kernel<BM, BN, WM, WN, BKM, NBUF, BKT>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
@@ -735,8 +751,19 @@ static int dispatch_igemm(const IgemmLaunch& L, int ntm, bool kmajor, bool vec, 
   static const char* noglds = getenv("SDM_IGEMM_GLDS");
   if (vec && !aff && !(noglds && noglds[0] == '0')) {
     constexpr int NBUF = (BM * BN >= 128 * 128) ? 2 : 3;
-    return kmajor ? launch_igemm_glds<BM, BN, WM, WN, true, NBUF>(L, ntm, st)
-                  : launch_igemm_glds<BM, BN, WM, WN, false, NBUF>(L, ntm, st);
+    static const char* bk64 = getenv("SDM_IGEMM_BK64");
+    if (BM * BN <= 64 * 128 && bk64 && bk64[0] != '0') {       // experimental: 64-deep K-steps for the small tiles
+      IgemmLaunch L2 = L;
+      L2.kchunks = cdiv(L.d.K, 64);
+      const int nb = bk64[0] == '3' ? 3 : 2;
+      if (nb == 3)
+        return kmajor ? launch_igemm_glds<BM, BN, WM, WN, true, 3, 64>(L2, ntm, st)
+                      : launch_igemm_glds<BM, BN, WM, WN, false, 3, 64>(L2, ntm, st);
+      return kmajor ? launch_igemm_glds<BM, BN, WM, WN, true, 2, 64>(L2, ntm, st)
+                    : launch_igemm_glds<BM, BN, WM, WN, false, 2, 64>(L2, ntm, st);
+    }
+    return kmajor ? launch_igemm_glds<BM, BN, WM, WN, true, NBUF, 32>(L, ntm, st)
+                  : launch_igemm_glds<BM, BN, WM, WN, false, NBUF, 32>(L, ntm, st);
   }
   // the affine-on-load variant exists only for K-contiguous weights (forward convs); other combinations never carry it
   if (aff) {
@@ -769,6 +796,20 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
   const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
   const int ntm = cdiv(d->M, kCfgs[cfg].bm);
   L.ntn = cdiv(d->N, kCfgs[cfg].bn);
+  {
+    // per-XCD L2 fill of the two tile orders: an XCD's run of c tiles spans (mt x nt) tiles of A rows / B columns
+    static const char* xo = getenv("SDM_IGEMM_XCD_ORDER");   // tuning override: "n" / "m"
+    const long c = cdiv((long)ntm * L.ntn, 8);
+    int taps_all = 0;                                        // phases sit in gridDim.y: same XCD as their tile
+    for (int ph = 0; ph < d->nphase; ++ph) taps_all += d->ntaps[ph];
+    const double a_tile = (double)kCfgs[cfg].bm * d->K, b_tile = (double)kCfgs[cfg].bn * d->K * taps_all;
+    const double nfast = (double)cdiv(c, L.ntn) * a_tile + (double)(c < L.ntn ? c : L.ntn) * b_tile;
+    const double mfast = (double)(c < ntm ? c : ntm) * a_tile + (double)cdiv(c, ntm) * b_tile;
+    L.mfast = mfast < nfast ? 1 : 0;
+    if (xo && xo[0] == 'n') L.mfast = 0;
+    if (xo && xo[0] == 'm') L.mfast = 1;
+    if (xo && xo[0] == '0') L.mfast = 2;                     // round-robin order as dispatched (for A/B measurements)
+  }
   const bool km = d->b_kmajor != 0;
   const bool aff = d->a.scale != nullptr;
   if (cfg == 0) rc = dispatch_igemm<128, 128, 2, 2>(L, ntm, km, vec, aff, st);
@@ -810,8 +851,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
-  const int tile_n = blockIdx.x % L.ntn, tile_m = blockIdx.x / L.ntn;
-  const int tp = blockIdx.y / L.splitk, ks = blockIdx.y % L.splitk;
+  // gridDim.x = pixel slices x tiles, slice-major behind the XCD remap: one XCD's L2 sees one contiguous range of
+  // pixels of both operands (for all tiles and, via gridDim.y, all taps) instead of every XCD streaming all of them
+  const int ntiles_ = gridDim.x / L.splitk;
+  const int wg_ = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int ks = wg_ / ntiles_, tile_ = wg_ - ks * ntiles_;
+  const int tile_n = tile_ % L.ntn, tile_m = tile_ / L.ntn;
+  const int tp = blockIdx.y;
   const int m0 = tile_m * BT, n0 = tile_n * BT;
   const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
   const float* g0 = d.g.p0 + b0 * d.g_bs0 + b1 * d.g_bs1;
@@ -993,8 +1039,13 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradLaunch L) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
-  const int tile_n = blockIdx.x % L.ntn, tile_m = blockIdx.x / L.ntn;
-  const int tp = blockIdx.y / L.splitk, ks = blockIdx.y % L.splitk;
+  // gridDim.x = pixel slices x tiles, slice-major behind the XCD remap: one XCD's L2 sees one contiguous range of
+  // pixels of both operands (for all tiles and, via gridDim.y, all taps) instead of every XCD streaming all of them
+  const int ntiles_ = gridDim.x / L.splitk;
+  const int wg_ = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int ks = wg_ / ntiles_, tile_ = wg_ - ks * ntiles_;
+  const int tile_n = tile_ % L.ntn, tile_m = tile_ / L.ntn;
+  const int tp = blockIdx.y;
   const int m0 = tile_m * BT, n0 = tile_n * BT;
   const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
   const float* g0 = d.g.p0 + b0 * d.g_bs0 + b1 * d.g_bs1;
@@ -1126,7 +1177,7 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradLaunch L) {
 template <int BT, int WM, int WN, int NBUF>
 static int launch_wgrad_glds(const WgradLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * NBUF * BK * BT * sizeof(float);
-  dim3 grid(ntm * L.ntn, L.d.ntaps * L.splitk, L.d.batch);
+  dim3 grid(ntm * L.ntn * L.splitk, L.d.ntaps, L.d.batch);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)wgrad_glds_kernel<BT, WM, WN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1157,7 +1208,7 @@ __global__ void zero_rows_kernel(float* p, long long rows, int cols, long long l
 template <int BT, int WM, int WN, bool VEC, bool AFF>
 static int launch_wgrad(const WgradLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = 4 * BK * BT * sizeof(float);
-  dim3 grid(ntm * L.ntn, L.d.ntaps * L.splitk, L.d.batch);
+  dim3 grid(ntm * L.ntn * L.splitk, L.d.ntaps, L.d.batch);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<BT, WM, WN, VEC, AFF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -114,13 +114,19 @@ class TapConv(nn.Module):
 
     def taps(self):
         """[taps, c_out, c_in] contiguous view of the weight storage (re-laid out once if something replaced it)."""
-        v = self._tapview(self.weight.data)
+        w = self._parameters["weight"]
+        cached = self.__dict__.get("_taps_cache")
+        if cached is not None and cached[0] == w.data_ptr() and cached[1] == w.device:
+            return cached[2]
+        v = self._tapview(w.data)
         if not v.is_contiguous():
             base = v.contiguous()
             self.weight.data = base.permute(3, 2, 0, 1) if self.kind == "ct4" else base.permute(2, 3, 0, 1)
             v = base
         k = v.shape[0]
-        return v.view(k * k, self.cout, self.cin)
+        v = v.view(k * k, self.cout, self.cin)
+        self.__dict__["_taps_cache"] = (self.weight.data_ptr(), self.weight.device, v)
+        return v
 
     def grad_taps(self, g):
         v = self._tapview(g)

@@ -12,8 +12,14 @@ from . import lib
 from .lib import ACT_NONE, ACT_SILU, ACT_TANH, IgemmDesc, Rows, WgradDesc
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # torch's current stream on the current device as a raw hipStream_t (the C accessors: the Python wrapper
+    # torch.cuda.current_stream() costs ~7 us, which at ~300 launches per step was a quarter of the host time)
+    return _raw_stream(_cur_device())
 
 
 def _p(t):
