@@ -295,6 +295,40 @@ int sdm_adam_multi(const sdm_adam_job* jobs_dev, int njobs, int64_t max_n, float
 /* hyper_dev (optional, DEVICE, 2 floats {lr, step}): when given, lr and the bias corrections 1-beta^step are read /
  * computed on the device, so a captured hipGraph of the training step can be replayed while lr and the step advance. */
 
+/* ---- bf16 storage path of the forward (sampling; BASELINE configs 3 and 5 name bf16) -------------------------------
+ * Activations and contraction weights are bf16 bit patterns (uint16_t) in HBM; accumulators, GroupNorm statistics,
+ * softmax, biases, modulation tables and the sampler state stay fp32.  The reference has no bf16 mode (its GPU path
+ * is fp16 autocast, train_diffusion.py:333): the parity gate of this path is rel-L2 <= 1e-2 against the fp32 oracle. */
+
+/* Same contraction as sdm_igemm with a.p0 / a.p1 / b / res / res2 (and out unless out_f32) pointing at bf16 data; every
+ * pitch and stride counts ELEMENTS.  Restrictions: b K-contiguous (b_kmajor = 0), K and csplit multiples of 8, rows
+ * 16-byte aligned, no affine-on-load / out_preact / dact_z (training features).  out_f32 != 0 writes fp32 (attention
+ * scores ahead of the softmax).  Split-K scratch: fp32, zero-filled, sdm_igemm_bf16_workspace_bytes(d). */
+int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t s);
+size_t sdm_igemm_bf16_workspace_bytes(const sdm_igemm_desc* d);
+/* fp32 -> bf16, round to nearest even (weights, once per checkpoint). */
+int sdm_cast_bf16(const float* src, uint16_t* dst, size_t n, sdm_stream_t s);
+/* sdm_stem_conv / sdm_head_conv with the NHWC side in bf16 (weights, bias and the NCHW image stay fp32). */
+int sdm_stem_conv_bf16(const float* x_nchw, const float* w_tap, const float* bias, uint16_t* out_nhwc,
+                       int images, int Cin, int H, int W, int Cout, int act, sdm_stream_t s);
+int sdm_head_conv_bf16(const uint16_t* x_nhwc, const float* w_tap, const float* bias, float* out_nchw,
+                       int images, int Cin, int H, int W, int Cout, int act, sdm_stream_t s);
+/* sdm_gn_affine on bf16 rows (fp32 tables out; mean / rstd are not returned: no backward on this path). */
+int sdm_gn_affine_bf16(const uint16_t* y, int64_t ldy, int images, int HW, int C, int groups, float eps,
+                       const float* gamma, const float* beta, const float* mod, int mod_nstride,
+                       float* scale, float* shift, sdm_stream_t s);
+/* out = scale*y + shift (+ cat(x0,x1)) on bf16 rows; x0 NULL = affine only (materialises the next conv's input). */
+int sdm_affine_residual_bf16(const uint16_t* y, int64_t ldy, const float* scale, const float* shift, int aff_nstride,
+                             const uint16_t* x0, int64_t ldx0, const uint16_t* x1, int64_t ldx1, int csplit,
+                             uint16_t* out, int64_t ldo, int images, int HW, int C, sdm_stream_t s);
+/* Column softmax (over queries i for every key j, custom_layers.py:147) of fp32 scores [batch][S][lds] into bf16
+ * probabilities [batch][S][ldp]; columns [S, ldp) are zero-filled (reduction padding of P.V). */
+int sdm_col_softmax_bf16(const float* scores, uint16_t* P, int batch, int S, int64_t lds, int64_t ldp, sdm_stream_t s);
+/* dst[b][c][r] = src[b / bdiv * src_bs0 + b % bdiv * src_bs1][r][c]; dst columns [R, ld_dst) zero-filled.  Puts V with
+ * the token index contiguous for P.V (the matrix cores take both operands contiguous along the reduction). */
+int sdm_transpose_bf16(const uint16_t* src, int64_t ld_src, int64_t src_bs0, int64_t src_bs1, int bdiv,
+                       uint16_t* dst, int64_t ld_dst, int64_t dst_bs, int batch, int R, int Cc, sdm_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

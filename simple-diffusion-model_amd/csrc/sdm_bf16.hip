@@ -1,0 +1,751 @@
+// bf16 storage path of the U-Net forward (sampling): activations and weights are bf16 in HBM, every sum is fp32
+// (matrix-core accumulators, GroupNorm statistics, softmax), biases / modulation tables / sampler state stay fp32.
+//
+//   v_mfma_f32_32x32x16_bf16: lane l (r = l&31, h = l>>5) supplies A[row r][k = 8h..8h+7] and B[k = 8h..8h+7][col r]
+//   -- one 16-byte chunk of a K-contiguous row each -- and the 32x32 fp32 result has col = lane&31,
+//   row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), exactly the layout of the fp32 path's 32x32x2 instruction.
+//
+// A K-step is 64 bf16 = 128 bytes per tile row, so the LDS image (128-byte rows, 16-byte chunks XOR-swizzled by
+// (row>>1)&7, filled by global_load_lds_dwordx4) is byte-for-byte the one of the fp32 kernel in sdm_igemm.hip; what
+// changes is the arithmetic density: a K-step is 4 MFMAs (128 cycles) per 32x32 tile instead of 16 (1024 cycles),
+// so the tiles are large (128x128 per workgroup, 64x64 per wave) and the ring is three K-steps deep.
+#include <stdlib.h>
+
+#include "sdm_common.h"
+
+typedef unsigned short bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {   // round to nearest even (v_cvt_pk_bf16_f32 on gfx950)
+  const __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+#define BKE 64   // reduction elements per K-step (128 bytes)
+#define ROWF 32  // floats per LDS tile row
+
+struct BfLaunch {
+  sdm_igemm_desc d;
+  int splitk, ntn, kchunks, mfast, out_f32;
+};
+
+__device__ float g_zero_chunk_bf[4];
+
+__device__ __forceinline__ int xcd_contiguous_bf(int bid, int total) {   // see sdm_igemm.hip
+  const int q = total >> 3, r = total & 7, x = bid & 7, i = bid >> 3;
+  return x < r ? x * (q + 1) + i : r * (q + 1) + (x - r) * q + i;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_bf() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// out[m][n] = act(alpha * sum_tap sum_k A[row(m,tap)][k] * B[tap][n][k] + bias[n]) (+ res) ; see sdm_igemm_desc.
+// 256 threads = 2x2 waves, each wave owns (BM/2)x(BN/2).
+template <int BM, int BN, int NBUF>
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(const BfLaunch L) {
+  const sdm_igemm_desc& d = L.d;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AIT = BM / 32, BIT = BN / 32;
+  constexpr int A_TILE = BM * ROWF, B_TILE = BN * ROWF;
+  constexpr int G = AIT + BIT;
+  constexpr int PD = NBUF - 1;
+  static_assert(PD >= 1 && PD <= 3, "ring depth");
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;
+  float* Bs = smem + NBUF * A_TILE;
+  long long* s_orow = (long long*)(Bs + NBUF * B_TILE);
+  int* s_tap = (int*)(s_orow + BM);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+  const int tile_id = xcd_contiguous_bf(blockIdx.x, gridDim.x), ntm_ = gridDim.x / L.ntn;
+  const int tile_n = L.mfast ? tile_id / ntm_ : tile_id % L.ntn, tile_m = L.mfast ? tile_id % ntm_ : tile_id / L.ntn;
+  const int phase = blockIdx.y / L.splitk, ks = blockIdx.y % L.splitk;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
+  const bf16_t* a0 = (const bf16_t*)d.a.p0 + b0 * d.a_bs0 + b1 * d.a_bs1;
+  const bf16_t* a1 = (const bf16_t*)d.a.p1;
+  const bf16_t* bw = (const bf16_t*)d.b + b0 * d.b_bs0 + b1 * d.b_bs1;
+  const int HtWt = d.Ht * d.Wt;
+  const int K = d.K, N = d.N, csplit = d.a.csplit;
+  const int arow = tid >> 3;
+  const int cc8 = 8 * ((tid & 7) ^ ((arow >> 1) & 7));   // logical chunk (in elements) behind this lane's physical slot
+  const int sw_l = (l31 >> 1) & 7;
+  const bf16_t* zero = (const bf16_t*)g_zero_chunk_bf;
+
+  for (int r = tid; r < BM; r += 256) {
+    const int m = m0 + r;
+    long long o = -1;
+    if (m < d.M) {
+      const int n = m / HtWt, rem = m - n * HtWt;
+      const int y = rem / d.Wt, x = rem - y * d.Wt;
+      const int oy = y * d.ostride + d.ph_oy[phase], ox = x * d.ostride + d.ph_ox[phase];
+      if (oy < d.Ho && ox < d.Wo) o = ((long long)n * d.Ho + oy) * d.Wo + ox;
+    }
+    s_orow[r] = o;
+  }
+  if (tid < SDM_MAX_TAPS) {
+    s_tap[tid] = d.tap_dy[phase][tid];
+    s_tap[SDM_MAX_TAPS + tid] = d.tap_dx[phase][tid];
+    s_tap[2 * SDM_MAX_TAPS + tid] = d.tap_w[phase][tid];
+  }
+  int a_ys[AIT], a_xs[AIT];
+  long long a_base[AIT];
+#pragma unroll
+  for (int i = 0; i < AIT; ++i) {
+    const int m = m0 + arow + 32 * i;
+    if (m < d.M) {
+      const int n = m / HtWt, rem = m - n * HtWt;
+      const int y = rem / d.Wt, x = rem - y * d.Wt;
+      a_ys[i] = y * d.sstride;
+      a_xs[i] = x * d.sstride;
+      a_base[i] = ((long long)n * d.a.H + a_ys[i]) * d.a.W + a_xs[i];
+    } else {
+      a_ys[i] = -(1 << 20); a_xs[i] = 0; a_base[i] = 0;
+    }
+  }
+  __syncthreads();
+
+  const int ntap = d.ntaps[phase];
+  const int kch = L.kchunks;
+  const int T = ntap * kch;
+  const int it0 = (int)((long long)T * ks / L.splitk), it1 = (int)((long long)T * (ks + 1) / L.splitk);
+
+  const bf16_t* pa0[AIT];
+  const bf16_t* pa1[AIT];
+  bool aok[AIT];
+  const bf16_t* pb[BIT];
+  bool bok[BIT];
+  auto setup_tap = [&](int tp) {
+    const int dy = s_tap[tp], dx = s_tap[SDM_MAX_TAPS + tp];
+    const bf16_t* bt = bw + (long long)s_tap[2 * SDM_MAX_TAPS + tp] * d.b_tap_stride;
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+      const int sy = a_ys[i] + dy, sx = a_xs[i] + dx;
+      aok[i] = (unsigned)sy < (unsigned)d.a.H && (unsigned)sx < (unsigned)d.a.W;
+      const long long row = a_base[i] + dy * d.a.W + dx;
+      pa0[i] = a0 + row * d.a.ld0 + cc8;
+      pa1[i] = a1 + row * d.a.ld1 + (cc8 - csplit);
+    }
+#pragma unroll
+    for (int i = 0; i < BIT; ++i) {
+      const int n = n0 + arow + 32 * i;
+      bok[i] = n < N;
+      pb[i] = bt + (long long)n * d.ldb + cc8;
+    }
+  };
+
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  auto issue = [&](int c0, int buf) {
+    const int c = c0 + cc8;
+    float* Ad = As + buf * A_TILE + __builtin_amdgcn_readfirstlane(wave) * 256;
+    float* Bd = Bs + buf * B_TILE + __builtin_amdgcn_readfirstlane(wave) * 256;
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+      const bool use = aok[i] && c < K;
+      const bf16_t* p = (c < csplit ? pa0[i] : pa1[i]) + c0;
+      p = use ? p : zero;
+      __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Ad + i * 32 * ROWF), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BIT; ++i) {
+      const bool use = bok[i] && c < K;
+      const bf16_t* p = use ? pb[i] + c0 : zero;
+      __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Bd + i * 32 * ROWF), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int tp = it0 / kch, kc = it0 - tp * kch;
+  int issued = it0;
+  auto issue_next = [&]() {
+    if (issued < it1) {
+      if (issued == it0) {
+        setup_tap(tp);
+      } else if (++kc == kch) {
+        kc = 0;
+        setup_tap(++tp);
+      }
+      issue(kc * BKE, (issued - it0) % NBUF);
+    }
+    ++issued;
+  };
+#pragma unroll
+  for (int p = 0; p < PD; ++p) issue_next();
+
+  for (int it = it0; it < it1; ++it) {
+    const int buf = (it - it0) % NBUF;
+    const int younger = (it1 - 1 - it) < (PD - 1) ? (it1 - 1 - it) : (PD - 1);
+    if (younger >= 2) wait_vmcnt_bf<2 * G>();
+    else if (younger == 1) wait_vmcnt_bf<G>();
+    else wait_vmcnt_bf<0>();
+    __builtin_amdgcn_s_barrier();
+    issue_next();
+    const float* Ab = As + buf * A_TILE + (wm * TM * 32 + l31) * ROWF;
+    const float* Bb = Bs + buf * B_TILE + (wn * TN * 32 + l31) * ROWF;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      const int ph = ((kg * 2 + h) ^ sw_l) * 4;
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(Ab + i * 32 * ROWF + ph);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4*)(Bb + j * 32 * ROWF + ph);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                              __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue
+  const long long obo = b0 * d.o_bs0 + b1 * d.o_bs1;
+  const long long rbo = b0 * d.r_bs0 + b1 * d.r_bs1;
+  bf16_t* out16 = (bf16_t*)d.out;
+  const bf16_t* res16 = (const bf16_t*)d.res;
+  const bf16_t* res216 = (const bf16_t*)d.res2;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + l31;
+      if (col >= N) continue;
+      const float bias = d.bias ? d.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long long orow = s_orow[row];
+        if (orow < 0) continue;
+        float v = acc[i][j][r];
+        if (L.splitk > 1) {
+          atomicAdd(&d.ws[orow * N + col], v);
+          continue;
+        }
+        v = sdm_act(v * d.alpha + bias, d.act);
+        if (res16) v += bf2f(res16[rbo + orow * d.ldres + col]);
+        if (res216) v += bf2f(res216[orow * d.ldres2 + col]);
+        if (L.out_f32) d.out[obo + orow * d.ldo + col] = v;
+        else out16[obo + orow * d.ldo + col] = f2bf(v);
+      }
+    }
+  }
+}
+
+// finishes a split-K contraction (ws [out row][N] raw fp32 sums, left zero-filled)
+__global__ __launch_bounds__(256) void splitk_epilogue_bf16_kernel(const sdm_igemm_desc d, long long rows, int out_f32) {
+  const long long total = rows * d.N;
+  bf16_t* out16 = (bf16_t*)d.out;
+  const bf16_t* res16 = (const bf16_t*)d.res;
+  const bf16_t* res216 = (const bf16_t*)d.res2;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long orow = e / d.N;
+    const int col = (int)(e - orow * d.N);
+    float v = d.ws[e] * d.alpha + (d.bias ? d.bias[col] : 0.f);
+    d.ws[e] = 0.f;
+    v = sdm_act(v, d.act);
+    if (res16) v += bf2f(res16[orow * d.ldres + col]);
+    if (res216) v += bf2f(res216[orow * d.ldres2 + col]);
+    if (out_f32) d.out[orow * d.ldo + col] = v;
+    else out16[orow * d.ldo + col] = f2bf(v);
+  }
+}
+
+static int bf_validate(const sdm_igemm_desc* d, int out_f32) {
+  SDM_CHECK_ARG(d != nullptr, "igemm_bf16: null desc");
+  SDM_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "igemm_bf16: bad M/N/K %d %d %d", d->M, d->N, d->K);
+  SDM_CHECK_ARG(d->batch >= 1 && d->bdiv >= 1, "igemm_bf16: bad batch");
+  SDM_CHECK_ARG(d->a.p0 && d->b && d->out, "igemm_bf16: null operand");
+  SDM_CHECK_ARG(d->Ht > 0 && d->Wt > 0 && d->M % (d->Ht * d->Wt) == 0, "igemm_bf16: M %d not a multiple of Ht*Wt", d->M);
+  SDM_CHECK_ARG(d->nphase >= 1 && d->nphase <= SDM_MAX_PHASE, "igemm_bf16: nphase");
+  for (int p = 0; p < d->nphase; ++p) SDM_CHECK_ARG(d->ntaps[p] >= 1 && d->ntaps[p] <= SDM_MAX_TAPS, "igemm_bf16: ntaps");
+  SDM_CHECK_ARG(d->a.p1 != nullptr || d->a.csplit >= d->K, "igemm_bf16: csplit < K without second source");
+  SDM_CHECK_ARG(d->K % 8 == 0 && (d->a.p1 == nullptr || d->a.csplit % 8 == 0), "igemm_bf16: K and the concat split must be multiples of 8");
+  SDM_CHECK_ARG(aligned16(d->a.p0) && d->a.ld0 % 8 == 0 && d->a_bs0 % 8 == 0 && d->a_bs1 % 8 == 0 &&
+                    (d->a.p1 == nullptr || (aligned16(d->a.p1) && d->a.ld1 % 8 == 0)),
+                "igemm_bf16: A rows must be 16-byte aligned (pitches multiples of 8 elements)");
+  SDM_CHECK_ARG(aligned16(d->b) && d->ldb % 8 == 0 && d->b_tap_stride % 8 == 0 && d->b_bs0 % 8 == 0 && d->b_bs1 % 8 == 0,
+                "igemm_bf16: B rows must be 16-byte aligned");
+  SDM_CHECK_ARG(d->b_kmajor == 0, "igemm_bf16: K-major B is not supported (transpose the operand: sdm_transpose_bf16)");
+  SDM_CHECK_ARG(d->a.scale == nullptr && d->out_preact == nullptr && d->dact_z == nullptr,
+                "igemm_bf16: affine-on-load / pre-activation output / dact are fp32-path (training) features");
+  SDM_CHECK_ARG(!(out_f32 && (d->res || d->res2)), "igemm_bf16: fp32 output takes no residual");
+  SDM_CHECK_ARG(d->ostride >= 1 && d->sstride >= 1 && d->Ho > 0 && d->Wo > 0, "igemm_bf16: bad strides/output dims");
+  SDM_CHECK_ARG(d->act >= 0 && d->act <= 2, "igemm_bf16: bad act");
+  return SDM_OK;
+}
+
+// tile / split-K choice: 128x128 tiles once they give most CUs a workgroup; else 64x64 tiles with enough K slices to
+// put ~2 workgroups on every CU while each still walks >= 4 K-steps.
+static void bf_plan(const sdm_igemm_desc* d, int* big, int* splitk, size_t* ws_need) {
+  static const char* force = getenv("SDM_BF16_FORCE");   // "big,splitk" tuning override
+  const long ph = (long)d->nphase * d->batch;
+  int maxtaps = 0;
+  for (int p = 0; p < d->nphase; ++p) maxtaps = d->ntaps[p] > maxtaps ? d->ntaps[p] : maxtaps;
+  const int T = maxtaps * cdiv(d->K, BKE);
+  const long t128 = (long)cdiv(d->M, 128) * cdiv(d->N, 128) * ph;
+  const long t64 = (long)cdiv(d->M, 64) * cdiv(d->N, 64) * ph;
+  int b = t128 >= 160 ? 1 : 0, sk = 1;
+  if (!b && t64 < 512) {
+    sk = (int)((512 + t64 - 1) / t64);
+    if (sk > T / 4) sk = T / 4;
+    if (sk > 64) sk = 64;
+    if (sk < 1) sk = 1;
+  }
+  if (force) {
+    int fb = 0, fs = 1;
+    if (sscanf(force, "%d,%d", &fb, &fs) == 2) { b = fb ? 1 : 0; sk = fs < 1 ? 1 : (fs > T ? T : fs); }
+  }
+  if (d->batch > 1 || d->nphase > 1) {
+    // split-K scratch is indexed [out row][N] of ONE problem: batched / multi-phase launches share out rows only when
+    // phases interleave into one output (conv-transpose) -- allowed -- but never across batch entries
+    if (d->batch > 1) sk = 1;
+  }
+  *big = b;
+  *splitk = sk;
+  const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
+  *ws_need = sk > 1 ? (size_t)out_rows * d->N * sizeof(float) : 0;
+}
+
+template <int BM, int BN, int NBUF>
+static int launch_bf(const BfLaunch& L, int ntm, hipStream_t st) {
+  constexpr size_t lds = (size_t)NBUF * (BM + BN) * ROWF * sizeof(float) + BM * sizeof(long long) + 3 * SDM_MAX_TAPS * sizeof(int);
+  static bool attr_set = false;
+  auto kern = igemm_bf16_kernel<BM, BN, NBUF>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(ntm * L.ntn, L.d.nphase * L.splitk, L.d.batch);
+  double taps = 0;
+  for (int p = 0; p < L.d.nphase; ++p) taps += L.d.ntaps[p];
+  {
+    const double images = (double)L.d.M / ((double)L.d.Ht * L.d.Wt);
+    const double in_b = images * L.d.a.H * L.d.a.W * L.d.K, w_b = (double)L.d.K * L.d.N * taps, out_b = images * L.d.Ho * L.d.Wo * L.d.N;
+    sdm_prof_shape(L.d.M, L.d.N, L.d.K, (int)taps, L.splitk, 2.0 * L.d.batch * (in_b + w_b + out_b));
+  }
+  sdm_prof_pre(st);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, L);
+  sdm_prof_post(st, BM == 128 ? 0 : 1, 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
+  SDM_CHECK_LAUNCH("igemm_bf16");
+  return SDM_OK;
+}
+
+extern "C" size_t sdm_igemm_bf16_workspace_bytes(const sdm_igemm_desc* d) {
+  if (bf_validate(d, 0) != SDM_OK) return 0;
+  int b, sk;
+  size_t need;
+  bf_plan(d, &b, &sk, &need);
+  return need;
+}
+
+extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t stream) {
+  int rc = bf_validate(d, out_f32);
+  if (rc != SDM_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  BfLaunch L;
+  L.d = *d;
+  L.out_f32 = out_f32 ? 1 : 0;
+  int big;
+  size_t need;
+  bf_plan(d, &big, &L.splitk, &need);
+  if (L.splitk > 1 && (d->ws == nullptr || d->ws_bytes < need)) L.splitk = 1;
+  L.kchunks = cdiv(d->K, BKE);
+  const int bm = big ? 128 : 64;
+  const int ntm = cdiv(d->M, bm);
+  L.ntn = cdiv(d->N, bm);
+  {
+    int taps_all = 0;
+    for (int ph = 0; ph < d->nphase; ++ph) taps_all += d->ntaps[ph];
+    const long c = cdiv((long)ntm * L.ntn, 8);
+    const double a_tile = (double)bm * d->K, b_tile = (double)bm * d->K * taps_all;
+    const double nfast = (double)cdiv(c, L.ntn) * a_tile + (double)(c < L.ntn ? c : L.ntn) * b_tile;
+    const double mfast = (double)(c < ntm ? c : ntm) * a_tile + (double)cdiv(c, ntm) * b_tile;
+    L.mfast = mfast < nfast ? 1 : 0;
+  }
+  static const char* nb = getenv("SDM_BF16_NBUF");
+  const bool nb4 = nb && nb[0] == '4';
+  if (big) rc = nb4 ? launch_bf<128, 128, 4>(L, ntm, st) : launch_bf<128, 128, 3>(L, ntm, st);
+  else rc = nb4 ? launch_bf<64, 64, 4>(L, ntm, st) : launch_bf<64, 64, 3>(L, ntm, st);
+  if (rc != SDM_OK) return rc;
+  if (L.splitk > 1) {
+    const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
+    const long long total = (long long)out_rows * d->N;
+    int grid = (int)((total + 1023) / 1024);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(splitk_epilogue_bf16_kernel, dim3(grid), dim3(256), 0, st, *d, (long long)out_rows, L.out_f32);
+    SDM_CHECK_LAUNCH("splitk_epilogue_bf16");
+  }
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// fp32 -> bf16 (weights, once per checkpoint), round to nearest even
+// --------------------------------------------------------------------------------------------
+__global__ void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = f2bf(src[i]);
+}
+
+extern "C" int sdm_cast_bf16(const float* src, uint16_t* dst, size_t n, sdm_stream_t s) {
+  SDM_CHECK_ARG(src && dst && n > 0, "cast_bf16: bad args");
+  size_t grid = (n + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)s, src, dst, n);
+  SDM_CHECK_LAUNCH("cast_bf16");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// edge convolutions: stem fp32 NCHW image -> bf16 rows (+SiLU); head bf16 rows -> fp32 NCHW (+Tanh).  fp32 weights.
+// --------------------------------------------------------------------------------------------
+#define STEM_PIX_BF 32
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                             int images, int H, int W, int Cout, int act) {
+  constexpr int K = CIN * 9;
+  __shared__ float patch[STEM_PIX_BF][K];
+  const long long P = (long long)images * H * W;
+  const long long p0 = (long long)blockIdx.x * STEM_PIX_BF;
+  for (int e = threadIdx.x; e < STEM_PIX_BF * K; e += 256) {
+    const int pi = e / K, k = e - pi * K;
+    const int ci = k / 9, tap = k - ci * 9;
+    const long long p = p0 + pi;
+    float v = 0.f;
+    if (p < P) {
+      const int n = (int)(p / (H * W)), rem = (int)(p - (long long)n * H * W);
+      const int y = rem / W + tap / 3 - 1, xx = rem % W + tap % 3 - 1;
+      if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = x[(((long long)n * CIN + ci) * H + y) * W + xx];
+    }
+    patch[pi][k] = v;
+  }
+  __syncthreads();
+  for (int co = threadIdx.x; co < Cout; co += 256) {
+    float wr[K];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) wr[ci * 9 + tap] = w[((long long)tap * Cout + co) * CIN + ci];
+    const float b = bias ? bias[co] : 0.f;
+    for (int pi = 0; pi < STEM_PIX_BF; ++pi) {
+      const long long p = p0 + pi;
+      if (p >= P) break;
+      float a = b;
+#pragma unroll
+      for (int k = 0; k < K; ++k) a = fmaf(patch[pi][k], wr[k], a);
+      out[p * Cout + co] = f2bf(sdm_act(a, act));
+    }
+  }
+}
+
+extern "C" int sdm_stem_conv_bf16(const float* x, const float* w, const float* bias, uint16_t* out, int images, int Cin,
+                                  int H, int W, int Cout, int act, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && w && out && images > 0 && H > 0 && W > 0 && Cout > 0, "stem_conv_bf16: bad args");
+  SDM_CHECK_ARG(Cin >= 1 && Cin <= 8, "stem_conv_bf16: Cin %d not in [1,8]", Cin);
+  const long long P = (long long)images * H * W;
+  const dim3 grid(cdiv(P, STEM_PIX_BF));
+#define STEM_BF(C) hipLaunchKernelGGL(stem_conv_bf16_kernel<C>, grid, dim3(256), 0, (hipStream_t)s, x, w, bias, out, images, H, W, Cout, act)
+  switch (Cin) {
+    case 1: STEM_BF(1); break;
+    case 2: STEM_BF(2); break;
+    case 3: STEM_BF(3); break;
+    case 4: STEM_BF(4); break;
+    case 5: STEM_BF(5); break;
+    case 6: STEM_BF(6); break;
+    case 7: STEM_BF(7); break;
+    default: STEM_BF(8); break;
+  }
+#undef STEM_BF
+  SDM_CHECK_LAUNCH("stem_conv_bf16");
+  return SDM_OK;
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void head_conv_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int images, int Cin, int H, int W, int act) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long P = (long long)images * H * W;
+  for (long long p = (long long)blockIdx.x * 4 + wave; p < P; p += (long long)gridDim.x * 4) {
+    const int n = (int)(p / (H * W)), rem = (int)(p - (long long)n * H * W);
+    const int y = rem / W, xx = rem % W;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int sy = y + tap / 3 - 1, sx = xx + tap % 3 - 1;
+      if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) continue;
+      const bf16_t* xr = x + (((long long)n * H + sy) * W + sx) * Cin;
+      for (int c = lane; c < Cin; c += 64) {
+        const float xv = bf2f(xr[c]);
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xv, w[((long long)tap * COUT + co) * Cin + c], acc[co]);
+      }
+    }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      const float v = wave_sum(acc[co]);
+      if (lane == co) out[(((long long)n * COUT + co) * H + y) * W + xx] = sdm_act(v + (bias ? bias[co] : 0.f), act);
+    }
+  }
+}
+
+extern "C" int sdm_head_conv_bf16(const uint16_t* x, const float* w, const float* bias, float* out, int images, int Cin,
+                                  int H, int W, int Cout, int act, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && w && out && images > 0 && H > 0 && W > 0 && Cin > 0, "head_conv_bf16: bad args");
+  SDM_CHECK_ARG(Cout >= 1 && Cout <= 8, "head_conv_bf16: Cout %d not in [1,8]", Cout);
+  const long long P = (long long)images * H * W;
+  int g = (int)((P + 3) / 4);
+  if (g > 8192) g = 8192;
+  const dim3 grid(g);
+#define HEAD_BF(C) hipLaunchKernelGGL(head_conv_bf16_kernel<C>, grid, dim3(256), 0, (hipStream_t)s, x, w, bias, out, images, Cin, H, W, act)
+  switch (Cout) {
+    case 1: HEAD_BF(1); break;
+    case 2: HEAD_BF(2); break;
+    case 3: HEAD_BF(3); break;
+    case 4: HEAD_BF(4); break;
+    case 5: HEAD_BF(5); break;
+    case 6: HEAD_BF(6); break;
+    case 7: HEAD_BF(7); break;
+    default: HEAD_BF(8); break;
+  }
+#undef HEAD_BF
+  SDM_CHECK_LAUNCH("head_conv_bf16");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// GroupNorm statistics (fp32 partials, fp64 totals) of bf16 rows folded with the AdaGN modulation; same tables as
+// sdm_gn_affine.  One workgroup per (image, group).
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void gn_affine_bf16_kernel(const bf16_t* __restrict__ y, long long ldy, int HW, int C,
+                                                              int groups, float eps, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ mod,
+                                                              int mod_ns, float* __restrict__ scale, float* __restrict__ shift,
+                                                              int vec) {
+  __shared__ double red[2][16];
+  const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cpg = C / groups;
+  const bf16_t* base = y + (long long)n * HW * ldy + g * cpg;
+  double s1 = 0.0, s2 = 0.0;
+  const long long total = (long long)HW * cpg;
+  if (vec) {   // cpg % 4 == 0, 8-byte aligned runs
+    const int q4 = cpg >> 2;
+    const long long tot4 = (long long)HW * q4;
+    for (long long e0 = threadIdx.x; e0 < tot4; e0 += 1024 * 8) {
+      float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long e = e0 + (long long)u * 1024;
+        if (e < tot4) {
+          const long long pix = e / q4;
+          const int c = (int)(e - pix * q4) * 4;
+          const u16x4 v = *(const u16x4*)(base + pix * ldy + c);
+          const float a = bf2f(v.x), b = bf2f(v.y), cc = bf2f(v.z), dd = bf2f(v.w);
+          p1 += (a + b) + (cc + dd);
+          p2 += (a * a + b * b) + (cc * cc + dd * dd);
+        }
+      }
+      s1 += p1;
+      s2 += p2;
+    }
+  } else {
+    for (long long e = threadIdx.x; e < total; e += 1024) {
+      const long long pix = e / cpg;
+      const int c = (int)(e - pix * cpg);
+      const double v = bf2f(base[pix * ldy + c]);
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+  __syncthreads();
+  s1 = 0.0;
+  s2 = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { s1 += red[0][w]; s2 += red[1][w]; }
+  const double mean = s1 / (double)total;
+  double var = s2 / (double)total - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float mu = (float)mean;
+  for (int c = threadIdx.x; c < cpg; c += 1024) {
+    const int ch = g * cpg + c;
+    const float ga = gamma[ch], be = beta[ch];
+    const float sm = mod ? mod[(long long)n * mod_ns + ch] : 1.f;
+    scale[(long long)n * C + ch] = rstd * ga * sm;
+    shift[(long long)n * C + ch] = mod ? (be - mu * rstd * ga) * sm + sm : (be - mu * rstd * ga);
+  }
+}
+
+extern "C" int sdm_gn_affine_bf16(const uint16_t* y, int64_t ldy, int images, int HW, int C, int groups, float eps,
+                                  const float* gamma, const float* beta, const float* mod, int mod_nstride, float* scale,
+                                  float* shift, sdm_stream_t s) {
+  SDM_CHECK_ARG(y && gamma && beta && scale && shift, "gn_affine_bf16: null pointer");
+  SDM_CHECK_ARG(images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_affine_bf16: C %d not divisible by groups %d", C, groups);
+  const int vec = ((C / groups) % 4 == 0) && ldy % 4 == 0 && (((uintptr_t)y) & 7) == 0;
+  hipLaunchKernelGGL(gn_affine_bf16_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, y, (long long)ldy, HW, C,
+                     groups, eps, gamma, beta, mod, mod_nstride, scale, shift, vec);
+  SDM_CHECK_LAUNCH("gn_affine_bf16");
+  return SDM_OK;
+}
+
+// out = scale*y + shift (+ cat(x0,x1)) on bf16 rows; x0 may be NULL (pure affine: the next conv's input)
+__global__ __launch_bounds__(256) void affine_residual_bf16_kernel(const bf16_t* __restrict__ y, long long ldy,
+                                                                   const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, int ans,
+                                                                   const bf16_t* __restrict__ x0, long long ldx0,
+                                                                   const bf16_t* __restrict__ x1, long long ldx1, int csplit,
+                                                                   bf16_t* __restrict__ out, long long ldo, long long rows,
+                                                                   int HW, int C) {
+  const int C8 = C >> 3;
+  const long long total = rows * C8;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long r = e / C8;
+    const int c = (int)(e - r * C8) * 8;
+    const int n = (int)(r / HW);
+    const u16x8 v = *(const u16x8*)(y + r * ldy + c);
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = bf2f(v[i]);
+    if (scale) {
+      const float* a = scale + (long long)n * ans + c;
+      const float* b = shift + (long long)n * ans + c;
+      const f32x4 a0 = *(const f32x4*)a, a1 = *(const f32x4*)(a + 4), b0 = *(const f32x4*)b, b1 = *(const f32x4*)(b + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f[i] = f[i] * a0[i] + b0[i];
+        f[4 + i] = f[4 + i] * a1[i] + b1[i];
+      }
+    }
+    if (x0) {
+      const u16x8 xv = (c < csplit) ? *(const u16x8*)(x0 + r * ldx0 + c) : *(const u16x8*)(x1 + r * ldx1 + (c - csplit));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] += bf2f(xv[i]);
+    }
+    u16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = f2bf(f[i]);
+    *(u16x8*)(out + r * ldo + c) = o;
+  }
+}
+
+extern "C" int sdm_affine_residual_bf16(const uint16_t* y, int64_t ldy, const float* scale, const float* shift,
+                                        int aff_nstride, const uint16_t* x0, int64_t ldx0, const uint16_t* x1, int64_t ldx1,
+                                        int csplit, uint16_t* out, int64_t ldo, int images, int HW, int C, sdm_stream_t s) {
+  SDM_CHECK_ARG(y && out && images > 0 && HW > 0 && C > 0, "affine_residual_bf16: bad args");
+  SDM_CHECK_ARG(x0 == nullptr || x1 != nullptr || csplit >= C, "affine_residual_bf16: csplit < C without second source");
+  SDM_CHECK_ARG(C % 8 == 0 && csplit % 8 == 0 && ldy % 8 == 0 && ldo % 8 == 0 && aff_nstride % 4 == 0 && aligned16(y) &&
+                    aligned16(out) && (x0 == nullptr || (aligned16(x0) && ldx0 % 8 == 0)) &&
+                    (x1 == nullptr || (aligned16(x1) && ldx1 % 8 == 0)) &&
+                    (scale == nullptr || (shift && aligned16(scale) && aligned16(shift))),
+                "affine_residual_bf16: rows must be 16-byte aligned, C a multiple of 8");
+  const long long rows = (long long)images * HW;
+  const long long work = rows * (C / 8);
+  int grid = (int)((work + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(affine_residual_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, y, (long long)ldy, scale, shift,
+                     aff_nstride, x0, (long long)ldx0, x1, (long long)ldx1, csplit, out, (long long)ldo, rows, HW, C);
+  SDM_CHECK_LAUNCH("affine_residual_bf16");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// column softmax of fp32 scores [batch][S][lds] -> bf16 probabilities [batch][S][ldp] (softmax over rows i for every
+// column j, custom_layers.py:147).  Columns j in [S, ldp) are written as zero (they are reduction padding for P.V).
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void col_softmax_bf16_kernel(const float* __restrict__ sc, bf16_t* __restrict__ P, int S,
+                                                               long long lds, long long ldp) {
+  __shared__ float sm[4][64], ss[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const float* base = sc + (long long)blockIdx.y * S * lds;
+  bf16_t* pb = P + (long long)blockIdx.y * S * ldp;
+  float m = -INFINITY, l = 0.f;
+  if (j < S) {
+    for (int i = wave; i < S; i += 4) {
+      const float v = base[(long long)i * lds + j];
+      if (v > m) {
+        l = l * __expf(m - v) + 1.f;
+        m = v;
+      } else {
+        l += __expf(v - m);
+      }
+    }
+  }
+  sm[wave][lane] = m;
+  ss[wave][lane] = l;
+  __syncthreads();
+  const float M = fmaxf(fmaxf(sm[0][lane], sm[1][lane]), fmaxf(sm[2][lane], sm[3][lane]));
+  float Lsum = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+    if (ss[w][lane] > 0.f) Lsum += ss[w][lane] * __expf(sm[w][lane] - M);
+  if (j < S) {
+    const float inv = 1.f / Lsum;
+    for (int i = wave; i < S; i += 4) pb[(long long)i * ldp + j] = f2bf(__expf(base[(long long)i * lds + j] - M) * inv);
+  } else if (j < ldp) {
+    for (int i = wave; i < S; i += 4) pb[(long long)i * ldp + j] = 0;
+  }
+}
+
+extern "C" int sdm_col_softmax_bf16(const float* scores, uint16_t* P, int batch, int S, int64_t lds, int64_t ldp,
+                                    sdm_stream_t s) {
+  SDM_CHECK_ARG(scores && P && batch > 0 && S > 0 && lds >= S && ldp >= S, "col_softmax_bf16: bad args");
+  hipLaunchKernelGGL(col_softmax_bf16_kernel, dim3(cdiv(ldp, 64), batch), dim3(256), 0, (hipStream_t)s, scores, P, S,
+                     (long long)lds, (long long)ldp);
+  SDM_CHECK_LAUNCH("col_softmax_bf16");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// batched transpose of bf16 matrices: dst[b][c][r] = src[b][r][c]  (r < R, c < Cc); dst columns [R, ldd) zero-filled.
+// Used for V in P.V: the matrix-core B operand must be contiguous along the reduction (token) index.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, long long lds, long long sb0,
+                                                             long long sb1, int bdiv, bf16_t* __restrict__ dst, long long ldd,
+                                                             long long dbs, int R, int Cc) {
+  __shared__ bf16_t tile[64][66];
+  const int b = blockIdx.z;
+  const bf16_t* s = src + (b / bdiv) * sb0 + (b % bdiv) * sb1;
+  bf16_t* dpt = dst + b * dbs;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < Cc) ? s[(long long)r * lds + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < Cc && r < ldd) dpt[(long long)c * ldd + r] = tile[tx][i];
+  }
+}
+
+extern "C" int sdm_transpose_bf16(const uint16_t* src, int64_t ld_src, int64_t src_bs0, int64_t src_bs1, int bdiv,
+                                  uint16_t* dst, int64_t ld_dst, int64_t dst_bs, int batch, int R, int Cc, sdm_stream_t s) {
+  SDM_CHECK_ARG(src && dst && batch > 0 && bdiv > 0 && R > 0 && Cc > 0 && ld_dst >= R && ld_src >= Cc, "transpose_bf16: bad args");
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(cdiv(Cc, 64), cdiv(ld_dst, 64), batch), dim3(256), 0, (hipStream_t)s, src,
+                     (long long)ld_src, (long long)src_bs0, (long long)src_bs1, bdiv, dst, (long long)ld_dst,
+                     (long long)dst_bs, R, Cc);
+  SDM_CHECK_LAUNCH("transpose_bf16");
+  return SDM_OK;
+}

@@ -12,6 +12,8 @@ gradient kernels and hands autograd one gradient tensor per live parameter.  The
 parameters of the reference (``adagn.y_shift.*``, ``attn_layers.*.norm.*``) receive ``None``
 exactly as they do there.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -46,6 +48,8 @@ class U_Net(nn.Module):
             ch.append(max_channel if c > max_channel else c)
         self.channel_layers = ch
         self.num_layers, self.image_recon = num_layers, image_recon
+        # storage type of no-grad forwards; SDM_INFER_DTYPE=bf16 selects the bf16 sampling path (set_inference_dtype)
+        self.inference_dtype = torch.bfloat16 if os.environ.get("SDM_INFER_DTYPE", "") == "bf16" else torch.float32
         self.in_channel, self.out_channel = in_channel, out_channel
 
         self.cond_emb = ConditionalEmbedding(time_dim, cond_dim) if time_dim is not None else None
@@ -143,7 +147,8 @@ class U_Net(nn.Module):
                     ctx.bank = self._bank.tables()
                     ctx.dmods = dict(zip(self._adagns, ctx.bank["dviews"]))
         stem = self.in_layer[0].conv_layer.conv
-        a = ops.stem_conv(x, stem.taps(), stem.bias, ACT_SILU, save_z=ctx.train)
+        a = ops.stem_conv(x, stem.taps(), stem.bias, ACT_SILU, save_z=ctx.train,
+                          out_dtype=torch.bfloat16 if ctx.bf16 else torch.float32)
         if ctx.train:
             ctx.rec["x"] = x
         a, _ = self.in_layer[1].run(ctx, a)
@@ -167,7 +172,16 @@ class U_Net(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             live = self.live_parameters()
             return _UNetFunction.apply(self, x, t, cond, *[p for _, p in live])
-        return self._run(RunCtx(False), x, t, cond)
+        return self._run(RunCtx(False, bf16=self.inference_dtype == torch.bfloat16), x, t, cond)
+
+    def set_inference_dtype(self, dtype):
+        """Storage type of activations / contraction weights for no-grad forwards (sampling): torch.float32 (default,
+        the parity path) or torch.bfloat16 (fp32 accumulation and statistics; rel-L2 ~ 3e-3 vs fp32).  Training and
+        autograd forwards are always fp32.  Additive API: the reference has no such switch."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("inference dtype must be torch.float32 or torch.bfloat16")
+        self.inference_dtype = dtype
+        return self
 
     def _edge_slab(self, dev):
         """Scratch for the per-workgroup partial slabs of the stem/head weight gradients (persistent: graph-safe)."""

@@ -39,14 +39,27 @@ class UNetBlockType(Enum):
 class RunCtx:
     """Per-forward execution context.  ``train`` keeps what backward needs in ``rec`` (module -> record)."""
 
-    def __init__(self, train=False):
+    def __init__(self, train=False, bf16=False):
         self.train = train
+        self.bf16 = bf16 and not train     # bf16 storage path: forward (sampling) only
         self.rec = {}
         self.emb = None
         self.demb = None
         self.mods = None      # {AdaGN: modulation rows} when the net evaluated all y_scale projections in one launch
         self.dmods = None     # {AdaGN: gradient rows} consumed by the batched y_scale data gradient
         self.bank = None      # the y_scale job tables this forward used (ops.LinearBank.tables())
+
+
+def bf16_weight(mod, key, src_fn):
+    """bf16 copy of a contraction weight for the sampling path, rebuilt when the fp32 master changed (in-place torch
+    updates bump ``_version``; the fused optimizer, which writes through raw pointers, bumps ops.WEIGHT_EPOCH)."""
+    w = mod._parameters["weight"]
+    tag = (w.data_ptr(), w._version, ops.WEIGHT_EPOCH[0])
+    cache = mod.__dict__.setdefault("_bf16_cache", {})
+    hit = cache.get(key)
+    if hit is None or hit[0] != tag:
+        cache[key] = hit = (tag, ops.to_bf16(src_fn()))
+    return hit[1]
 
 
 def to_rows(x_nchw):
@@ -80,6 +93,9 @@ class TapLinear(nn.Module):
         self.weight = nn.Parameter(ref.weight.detach().clone())
         self.bias = nn.Parameter(ref.bias.detach().clone())
         self.in_features, self.out_features = in_features, out_features
+
+    def weight_for(self, ctx):
+        return bf16_weight(self, "w", lambda: self.weight) if ctx.bf16 else self.weight
 
 
 class TapNorm(nn.Module):
@@ -127,6 +143,9 @@ class TapConv(nn.Module):
         v = v.view(k * k, self.cout, self.cin)
         self.__dict__["_taps_cache"] = (self.weight.data_ptr(), self.weight.device, v)
         return v
+
+    def taps_for(self, ctx):
+        return bf16_weight(self, "taps", self.taps) if ctx.bf16 else self.taps()
 
     def grad_taps(self, g):
         v = self._tapview(g)
@@ -268,7 +287,11 @@ class AttentionBlock(nn.Module):
 
     def run(self, ctx, x):
         S = x.h * x.w
-        qkv = ops.linear_rows(x.t, self.projection.weight, self.projection.bias)
+        qkv = ops.linear_rows(x.t, self.projection.weight_for(ctx), self.projection.bias)
+        if ctx.bf16:
+            res = ops.attention_core_fwd_bf16(qkv, x.n, S, self.heads, self.d_k)
+            out = ops.linear_rows(res, self.output.weight_for(ctx), self.output.bias, res=x.t)
+            return Act(out, x.n, x.h, x.w)
         res, P = ops.attention_core_fwd(qkv, x.n, S, self.heads, self.d_k)
         out = ops.linear_rows(res, self.output.weight, self.output.bias, res=x.t)
         if ctx.train:
@@ -318,7 +341,7 @@ class _ResampleBlock(nn.Module):
 
     def run(self, ctx, x, emb=None):
         c = self.conv_layer.conv
-        y = ops.conv_fwd(x, c.taps(), c.bias, self.kind, ACT_SILU, save_z=ctx.train)
+        y = ops.conv_fwd(x, c.taps_for(ctx), c.bias, self.kind, ACT_SILU, save_z=ctx.train)
         if ctx.train:
             ctx.rec[self] = (x, y)
         return y
@@ -353,7 +376,7 @@ class UNet_ConvBlock(nn.Module):
     def run(self, ctx, x, emb=None):
         c = self.conv_layer.conv
         act = ACT_SILU if self.use_activation else ACT_NONE
-        y = ops.conv_fwd(x, c.taps(), c.bias, "c3s1", act, save_z=ctx.train and self.use_activation)
+        y = ops.conv_fwd(x, c.taps_for(ctx), c.bias, "c3s1", act, save_z=ctx.train and self.use_activation)
         if emb is None or not hasattr(self, "adagn"):
             if ctx.train:
                 ctx.rec[self] = (x, y, None, None, None)
@@ -390,7 +413,10 @@ class ResidualBlock(nn.Module):
 
     def run(self, ctx, x, emb=None):
         y1, aff1 = self.conv_block_1.run(ctx, x, emb)
-        x2 = y1 if aff1 is None else Act(y1.t, y1.n, y1.h, y1.w, scale=aff1[0], shift=aff1[1])
+        if ctx.bf16 and aff1 is not None:      # bf16 rows: the affine is materialised (the LDS-DMA tiles cannot apply it)
+            x2 = ops.affine_residual(y1, aff1[0], aff1[1], None)
+        else:
+            x2 = y1 if aff1 is None else Act(y1.t, y1.n, y1.h, y1.w, scale=aff1[0], shift=aff1[1])
         y2, aff2 = self.conv_block_2.run(ctx, x2, emb)
         s2, h2 = (None, None) if aff2 is None else aff2
         return ops.affine_residual(y2, s2, h2, x)

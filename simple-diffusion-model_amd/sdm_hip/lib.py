@@ -118,6 +118,16 @@ _PROTOS = {
     "sdm_area_resize": (_i, [fp, fp, _i, _i, _i, _i, _i, fp]),
     "sdm_step_advance": (_i, [fp, fp, fp, _i, _i, fp, fp, fp]),
     "sdm_adam_multi": (_i, [fp, _i, _i64, _f, _f, _f, _f, _f, _f, _f, fp, fp]),
+    # bf16 storage path (forward / sampling)
+    "sdm_igemm_bf16": (_i, [C.POINTER(IgemmDesc), _i, fp]),
+    "sdm_igemm_bf16_workspace_bytes": (_sz, [C.POINTER(IgemmDesc)]),
+    "sdm_cast_bf16": (_i, [fp, fp, _sz, fp]),
+    "sdm_stem_conv_bf16": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
+    "sdm_head_conv_bf16": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
+    "sdm_gn_affine_bf16": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, fp, fp]),
+    "sdm_affine_residual_bf16": (_i, [fp, _i64, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, _i, _i, _i, fp]),
+    "sdm_col_softmax_bf16": (_i, [fp, fp, _i, _i, _i64, _i64, fp]),
+    "sdm_transpose_bf16": (_i, [fp, _i64, _i64, _i64, _i, fp, _i64, _i64, _i, _i, _i, fp]),
 }
 EXPORTS = tuple(_PROTOS)
 

@@ -154,12 +154,29 @@ def _set_taps(d, phase, taps):
         d.tap_dy[phase][i], d.tap_dx[phase][i], d.tap_w[phase][i] = dy, dx, w
 
 
-def _launch_igemm(d, device):
-    need = lib.raw("sdm_igemm_workspace_bytes")(C.byref(d))
+BF16 = torch.bfloat16
+WEIGHT_EPOCH = [0]      # bumped whenever weights are rewritten behind torch's back (fused Adam): bf16 copies go stale
+
+
+def _launch_igemm(d, device, bf16=False, out_f32=False):
+    """bf16=True: operands (and the output unless out_f32) are bf16, see sdm_igemm_bf16 (forward / sampling path)."""
+    need = lib.raw("sdm_igemm_bf16_workspace_bytes" if bf16 else "sdm_igemm_workspace_bytes")(C.byref(d))
     ws = WS.get(need, device)
     d.ws = _p(ws)
     d.ws_bytes = ws.numel() * 4 if ws is not None else 0
-    lib.call("sdm_igemm", C.byref(d), _stream())
+    if bf16:
+        lib.call("sdm_igemm_bf16", C.byref(d), int(out_f32), _stream())
+    else:
+        lib.call("sdm_igemm", C.byref(d), _stream())
+
+
+def to_bf16(t):
+    """Round-to-nearest-even bf16 copy of an fp32 tensor, keeping its memory layout (weights, once per checkpoint)."""
+    src = t.detach()
+    flat = torch.empty(src.numel(), dtype=BF16, device=src.device)
+    dense = src.as_strided((src.numel(),), (1,)) if not src.is_contiguous() else src.reshape(-1)
+    lib.call("sdm_cast_bf16", _p(dense), _p(flat), src.numel(), _stream())
+    return flat.as_strided(src.shape, src.stride())
 
 
 def _base_desc(M, N, K):
@@ -185,7 +202,10 @@ def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False):
     T, cout, cin = wt.shape
     assert cin == x.c, (cin, x.c)
     ho, wo = conv_out_hw(x.h, x.w, kind)
-    out = torch.empty((x.n * ho * wo, cout), dtype=torch.float32, device=wt.device)
+    bf = wt.dtype == BF16
+    if bf and (save_z or x.scale is not None or x.t.dtype != BF16):
+        raise lib.SdmError("bf16 conv: forward-only path on plain bf16 rows")
+    out = torch.empty((x.n * ho * wo, cout), dtype=wt.dtype, device=wt.device)
     z = torch.empty_like(out) if save_z else None
     if kind == "ct4":
         d = _base_desc(x.rows, cout, cin)
@@ -206,7 +226,7 @@ def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False):
     d.Ho, d.Wo = ho, wo
     d.out, d.ldo = _p(out), out.stride(0)
     d.bias, d.act, d.out_preact = _p(bias), act, _p(z)
-    _launch_igemm(d, wt.device)
+    _launch_igemm(d, wt.device, bf16=bf)
     return Act(out, x.n, ho, wo, z=z)
 
 
@@ -288,8 +308,11 @@ def linear_rows(x, W, b, act=ACT_NONE, res=None, save_z=False, out=None):
     """Token linear on the matrix cores: x [rows, K] (any pitch) @ W[O, K]^T + b (+ res)."""
     rows, K = x.shape
     O = W.shape[0]
+    bf = W.dtype == BF16
+    if bf and (save_z or x.dtype != BF16 or (res is not None and res.dtype != BF16)):
+        raise lib.SdmError("bf16 linear: forward-only path on bf16 rows")
     if out is None:
-        out = torch.empty((rows, O), dtype=torch.float32, device=x.device)
+        out = torch.empty((rows, O), dtype=W.dtype, device=x.device)
     d = _base_desc(rows, O, K)
     d.Ht, d.Wt = rows, 1
     plain_rows(d.a, x)
@@ -300,7 +323,7 @@ def linear_rows(x, W, b, act=ACT_NONE, res=None, save_z=False, out=None):
     d.bias, d.act = _p(b), act
     if res is not None:
         d.res, d.ldres = _p(res), res.stride(0)
-    _launch_igemm(d, x.device)
+    _launch_igemm(d, x.device, bf16=bf)
     return out
 
 
@@ -380,6 +403,50 @@ def attention_core_fwd(qkv, n, S, heads, dk):
     return res, P
 
 
+def _pad8(s):
+    return (s + 7) // 8 * 8
+
+
+def attention_core_fwd_bf16(qkv, n, S, heads, dk):
+    """bf16 form of attention_core_fwd (forward only): scores are produced in fp32, the column softmax writes bf16
+    probabilities, V is transposed once so that P.V contracts two token-contiguous operands.  Returns res bf16."""
+    dev = qkv.device
+    Sp = _pad8(S)
+    ld = qkv.stride(0)
+    scores = torch.empty((n * heads, S, Sp), dtype=torch.float32, device=dev)
+    d = _base_desc(S, S, dk)
+    d.batch, d.bdiv = n * heads, heads
+    d.Ht, d.Wt = S, 1
+    plain_rows(d.a, qkv, rows=S)
+    d.a_bs0, d.a_bs1 = S * ld, 3 * dk
+    d.b, d.ldb, d.b_kmajor = qkv.data_ptr() + 2 * dk, ld, 0
+    d.b_bs0, d.b_bs1 = S * ld, 3 * dk
+    d.ntaps[0] = 1
+    d.Ho, d.Wo = S, 1
+    d.out, d.ldo, d.o_bs0, d.o_bs1 = _p(scores), Sp, heads * S * Sp, S * Sp
+    d.alpha = float(dk) ** -0.5
+    _launch_igemm(d, dev, bf16=True, out_f32=True)
+    P = torch.empty((n * heads, S, Sp), dtype=BF16, device=dev)
+    lib.call("sdm_col_softmax_bf16", _p(scores), _p(P), n * heads, S, Sp, Sp, _stream())
+    Vt = torch.empty((n * heads, dk, Sp), dtype=BF16, device=dev)
+    lib.call("sdm_transpose_bf16", qkv.data_ptr() + 4 * dk, ld, S * ld, 3 * dk, heads, _p(Vt), Sp, dk * Sp, n * heads, S, dk,
+             _stream())
+    res = torch.empty((n * S, heads * dk), dtype=BF16, device=dev)
+    d = _base_desc(S, dk, Sp)
+    d.batch, d.bdiv = n * heads, heads
+    d.Ht, d.Wt = S, 1
+    plain_rows(d.a, P[0], rows=S)
+    d.a.ld0 = Sp
+    d.a_bs0, d.a_bs1 = heads * S * Sp, S * Sp
+    d.b, d.ldb, d.b_kmajor = _p(Vt), Sp, 0
+    d.b_bs0, d.b_bs1 = heads * dk * Sp, dk * Sp
+    d.ntaps[0] = 1
+    d.Ho, d.Wo = S, 1
+    d.out, d.ldo, d.o_bs0, d.o_bs1 = _p(res), heads * dk, S * heads * dk, dk
+    _launch_igemm(d, dev, bf16=True)
+    return res
+
+
 def attention_core_bwd(dres, qkv, P, n, S, heads, dk):
     """Returns dqkv [n*S, heads*3*dk] given dres [n*S, heads*dk]."""
     dev = qkv.device
@@ -450,9 +517,13 @@ def attention_core_bwd(dres, qkv, P, n, S, heads, dk):
 
 
 # ---- pointwise / reductions -------------------------------------------------------------------
-def stem_conv(x_nchw, wt, bias, act=ACT_SILU, save_z=False):
+def stem_conv(x_nchw, wt, bias, act=ACT_SILU, save_z=False, out_dtype=torch.float32):
     n, cin, h, w = x_nchw.shape
     cout = wt.shape[1]
+    if out_dtype == BF16:
+        out = torch.empty((n * h * w, cout), dtype=BF16, device=wt.device)
+        lib.call("sdm_stem_conv_bf16", _p(x_nchw), _p(wt), _p(bias), _p(out), n, cin, h, w, cout, act, _stream())
+        return Act(out, n, h, w)
     out = torch.empty((n * h * w, cout), dtype=torch.float32, device=wt.device)
     z = torch.empty_like(out) if save_z else None
     lib.call("sdm_stem_conv", _p(x_nchw), _p(wt), _p(bias), _p(out), _p(z), n, cin, h, w, cout, act, _stream())
@@ -462,6 +533,9 @@ def stem_conv(x_nchw, wt, bias, act=ACT_SILU, save_z=False):
 def head_conv(x, wt, bias, act=ACT_NONE):
     cout = wt.shape[1]
     out = torch.empty((x.n, cout, x.h, x.w), dtype=torch.float32, device=wt.device)
+    if x.t.dtype == BF16:
+        lib.call("sdm_head_conv_bf16", _p(x.t), _p(wt), _p(bias), _p(out), x.n, x.c, x.h, x.w, cout, act, _stream())
+        return out
     lib.call("sdm_head_conv", _p(x.t), _p(wt), _p(bias), _p(out), x.n, x.c, x.h, x.w, cout, act, _stream())
     return out
 
@@ -472,6 +546,11 @@ def gn_affine(y, gamma, beta, mod, groups=32, eps=1e-5):
     dev = y.t.device
     scale = torch.empty((y.n, C_), dtype=torch.float32, device=dev)
     shift = torch.empty_like(scale)
+    mns = 0 if (mod is None or mod.shape[0] == 1) else mod.stride(0)
+    if y.t.dtype == BF16:
+        lib.call("sdm_gn_affine_bf16", _p(y.t), y.t.stride(0), y.n, y.h * y.w, C_, groups, eps, _p(gamma), _p(beta), _p(mod),
+                 mns, _p(scale), _p(shift), _stream())
+        return scale, shift, None, None
     mean = torch.empty((y.n, groups), dtype=torch.float32, device=dev)
     rstd = torch.empty_like(mean)
     mns = 0 if (mod is None or mod.shape[0] == 1) else mod.stride(0)
@@ -481,9 +560,17 @@ def gn_affine(y, gamma, beta, mod, groups=32, eps=1e-5):
 
 
 def affine_residual(y, scale, shift, x):
-    """out = scale*y + shift + cat(x.t, x.t2)  (plain Act)."""
-    out = torch.empty((y.rows, y.c), dtype=torch.float32, device=y.t.device)
+    """out = scale*y + shift + cat(x.t, x.t2)  (plain Act).  bf16 rows: x may be None (affine only)."""
     ans = 0 if (scale is None or scale.shape[0] == 1) else scale.stride(0)
+    if y.t.dtype == BF16:
+        out = torch.empty((y.rows, y.c), dtype=BF16, device=y.t.device)
+        x0 = None if x is None else x.t
+        x1 = None if x is None else x.t2
+        lib.call("sdm_affine_residual_bf16", _p(y.t), y.t.stride(0), _p(scale), _p(shift), ans, _p(x0),
+                 x0.stride(0) if x0 is not None else 0, _p(x1), x1.stride(0) if x1 is not None else 0,
+                 x.c1 if x1 is not None else (1 << 30), _p(out), out.stride(0), y.n, y.h * y.w, y.c, _stream())
+        return Act(out, y.n, y.h, y.w)
+    out = torch.empty((y.rows, y.c), dtype=torch.float32, device=y.t.device)
     lib.call("sdm_affine_residual", _p(y.t), y.t.stride(0), _p(scale), _p(shift), ans, _p(x.t), x.t.stride(0), _p(x.t2),
              x.t2.stride(0) if x.t2 is not None else 0, x.c1 if x.t2 is not None else (1 << 30), _p(out), out.stride(0),
              y.n, y.h * y.w, y.c, _stream())

@@ -48,6 +48,7 @@ class FusedAdam:
         ``hyper`` (device [lr, step]) makes lr / bias corrections device-resident (graph replay)."""
         if advance:
             self.step_count += 1
+        ops.WEIGHT_EPOCH[0] += 1                      # weights change behind torch's version counters
         count = self.njobs - first if count is None else count
         lr = self.param_groups[0]["lr"]
         b1, b2 = self.betas
