@@ -149,7 +149,7 @@ def main():
     print(f"[bench] rank {rank}: {args.steps} train steps in {dt:.3f}s", file=sys.stderr, flush=True)
 
     # ---- sampling rate of the hipGraph-captured DDPM step (rank 0 only, replicas need no collective)
-    sample_rate = None
+    sample_rate = sample_rate_bf16 = None
     if args.sample_steps > 0 and rank == 0:
         xT = torch.randn(args.batch, 3, args.res, args.res, device=dev, generator=g)
         quiet = lambda *a, **k: None
@@ -159,7 +159,16 @@ def main():
         S.ddpm_sampling(net, sched, xT, 1, args.sample_steps, device="cuda", log=quiet)
         torch.cuda.synchronize()
         sample_rate = args.sample_steps / (time.perf_counter() - ts)     # includes one capture; amortised over T
-        print(f"[bench] sampling: {sample_rate:.1f} steps/s", file=sys.stderr, flush=True)
+        # same sampler with the U-Net in bf16 storage (fp32 accumulation / statistics / sampler state)
+        net.set_inference_dtype(torch.bfloat16)
+        S.ddpm_sampling(net, sched, xT, 1, 4, device="cuda", log=quiet)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        S.ddpm_sampling(net, sched, xT, 1, args.sample_steps, device="cuda", log=quiet)
+        torch.cuda.synchronize()
+        sample_rate_bf16 = args.sample_steps / (time.perf_counter() - ts)
+        net.set_inference_dtype(torch.float32)
+        print(f"[bench] sampling: {sample_rate:.1f} steps/s fp32, {sample_rate_bf16:.1f} steps/s bf16", file=sys.stderr, flush=True)
 
     if world > 1:
         dist.barrier()                      # rank 0 may still have been sampling
@@ -197,6 +206,7 @@ def main():
         "train_step_hipgraph": bool(graphed),
         "step_tflops_algorithmic": step_flops / (dt / args.steps) / 1e12,
         "sample_steps_per_s": sample_rate,
+        "sample_steps_per_s_bf16": sample_rate_bf16,
         "sample_config": None if sample_rate is None else "DDPM hipGraph step, batch %d, %d steps timed incl. capture"
                                                           % (args.batch, args.sample_steps),
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

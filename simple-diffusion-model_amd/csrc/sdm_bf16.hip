@@ -8,7 +8,7 @@
 // A K-step is 64 bf16 = 128 bytes per tile row, so the LDS image (128-byte rows, 16-byte chunks XOR-swizzled by
 // (row>>1)&7, filled by global_load_lds_dwordx4) is byte-for-byte the one of the fp32 kernel in sdm_igemm.hip; what
 // changes is the arithmetic density: a K-step is 4 MFMAs (128 cycles) per 32x32 tile instead of 16 (1024 cycles),
-// so the tiles are large (128x128 per workgroup, 64x64 per wave) and the ring is three K-steps deep.
+// so operand movement, not the matrix pipe, sets the pace (see the tile configurations below).
 #include <stdlib.h>
 
 #include "sdm_common.h"
@@ -46,11 +46,17 @@ __device__ __forceinline__ void wait_vmcnt_bf() {
 
 // out[m][n] = act(alpha * sum_tap sum_k A[row(m,tap)][k] * B[tap][n][k] + bias[n]) (+ res) ; see sdm_igemm_desc.
 // 256 threads = 2x2 waves, each wave owns (BM/2)x(BN/2).
-template <int BM, int BN, int NBUF>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(const BfLaunch L) {
+// FAST: K and the concat split are multiples of the 64-element K-step, so a K-step never straddles the reduction end or
+// the two concatenated sources; the DMA addresses are then per-lane pointers advanced by one add per K-step (rows outside
+// the image point at a zero chunk with step 0) and rebuilt only when the (tap, source) segment changes.
+template <int BM, int BN, int WM, int WN, int NBUF, bool FAST>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch L) {
   const sdm_igemm_desc& d = L.d;
-  constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int AIT = BM / 32, BIT = BN / 32;
+  constexpr int NT = 64 * WM * WN;              // threads: WM x WN waves, each owning (BM/WM) x (BN/WN)
+  constexpr int RA = NT / 8;                    // tile rows covered by one pass of the NT threads (8 chunks per row)
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int AIT = BM / RA, BIT = BN / RA;
+  static_assert(RA % 16 == 0 && BM % RA == 0 && BN % RA == 0, "pass geometry");
   constexpr int A_TILE = BM * ROWF, B_TILE = BN * ROWF;
   constexpr int G = AIT + BIT;
   constexpr int PD = NBUF - 1;
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const BfLaunch L) {
   int* s_tap = (int*)(s_orow + BM);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
   const int tile_id = xcd_contiguous_bf(blockIdx.x, gridDim.x), ntm_ = gridDim.x / L.ntn;
   const int tile_n = L.mfast ? tile_id / ntm_ : tile_id % L.ntn, tile_m = L.mfast ? tile_id % ntm_ : tile_id / L.ntn;
   const int phase = blockIdx.y / L.splitk, ks = blockIdx.y % L.splitk;
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const BfLaunch L) {
   const int sw_l = (l31 >> 1) & 7;
   const bf16_t* zero = (const bf16_t*)g_zero_chunk_bf;
 
-  for (int r = tid; r < BM; r += 256) {
+  for (int r = tid; r < BM; r += NT) {
     const int m = m0 + r;
     long long o = -1;
     if (m < d.M) {
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const BfLaunch L) {
   long long a_base[AIT];
 #pragma unroll
   for (int i = 0; i < AIT; ++i) {
-    const int m = m0 + arow + 32 * i;
+    const int m = m0 + arow + RA * i;
     if (m < d.M) {
       const int n = m / HtWt, rem = m - n * HtWt;
       const int y = rem / d.Wt, x = rem - y * d.Wt;
@@ -116,11 +122,16 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const BfLaunch L) {
   const int T = ntap * kch;
   const int it0 = (int)((long long)T * ks / L.splitk), it1 = (int)((long long)T * (ks + 1) / L.splitk);
 
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
   const bf16_t* pa0[AIT];
   const bf16_t* pa1[AIT];
   bool aok[AIT];
   const bf16_t* pb[BIT];
   bool bok[BIT];
+  int astep[AIT], bstep[BIT];          // FAST: elements to advance per K-step (64, or 0 for the zero chunk)
+  const int kch0 = (csplit < K ? csplit : K) / BKE;   // FAST: K-steps served by the first source
+  // general path: per-tap pointers, every K-step re-derives source / validity / tail
   auto setup_tap = [&](int tp) {
     const int dy = s_tap[tp], dx = s_tap[SDM_MAX_TAPS + tp];
     const bf16_t* bt = bw + (long long)s_tap[2 * SDM_MAX_TAPS + tp] * d.b_tap_stride;
@@ -134,30 +145,63 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const BfLaunch L) {
     }
 #pragma unroll
     for (int i = 0; i < BIT; ++i) {
-      const int n = n0 + arow + 32 * i;
+      const int n = n0 + arow + RA * i;
       bok[i] = n < N;
       pb[i] = bt + (long long)n * d.ldb + cc8;
     }
   };
+  // FAST path: pointers of segment (tap tp, starting at K-step kc of that tap)
+  auto setup_seg = [&](int tp, int kc) {
+    const int dy = s_tap[tp], dx = s_tap[SDM_MAX_TAPS + tp];
+    const bf16_t* bt = bw + (long long)s_tap[2 * SDM_MAX_TAPS + tp] * d.b_tap_stride + kc * BKE + cc8;
+    const bool second = kc >= kch0;
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+      const int sy = a_ys[i] + dy, sx = a_xs[i] + dx;
+      const bool ok = (unsigned)sy < (unsigned)d.a.H && (unsigned)sx < (unsigned)d.a.W;
+      const long long row = a_base[i] + dy * d.a.W + dx;
+      const bf16_t* p = second ? a1 + row * d.a.ld1 + ((kc - kch0) * BKE + cc8) : a0 + row * d.a.ld0 + (kc * BKE + cc8);
+      pa0[i] = ok ? p : zero;
+      astep[i] = ok ? BKE : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < BIT; ++i) {
+      const int n = n0 + arow + RA * i;
+      const bool ok = n < N;
+      pb[i] = ok ? bt + (long long)n * d.ldb : zero;
+      bstep[i] = ok ? BKE : 0;
+    }
+  };
 
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-  typedef const __attribute__((address_space(1))) void* glb_ptr;
   auto issue = [&](int c0, int buf) {
-    const int c = c0 + cc8;
     float* Ad = As + buf * A_TILE + __builtin_amdgcn_readfirstlane(wave) * 256;
     float* Bd = Bs + buf * B_TILE + __builtin_amdgcn_readfirstlane(wave) * 256;
+    if (FAST) {
+#pragma unroll
+      for (int i = 0; i < AIT; ++i) {
+        __builtin_amdgcn_global_load_lds((glb_ptr)pa0[i], (lds_ptr)(Ad + i * RA * ROWF), 16, 0, 0);
+        pa0[i] += astep[i];
+      }
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) {
+        __builtin_amdgcn_global_load_lds((glb_ptr)pb[i], (lds_ptr)(Bd + i * RA * ROWF), 16, 0, 0);
+        pb[i] += bstep[i];
+      }
+      return;
+    }
+    const int c = c0 + cc8;
 #pragma unroll
     for (int i = 0; i < AIT; ++i) {
       const bool use = aok[i] && c < K;
       const bf16_t* p = (c < csplit ? pa0[i] : pa1[i]) + c0;
       p = use ? p : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Ad + i * 32 * ROWF), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Ad + i * RA * ROWF), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BIT; ++i) {
       const bool use = bok[i] && c < K;
       const bf16_t* p = use ? pb[i] + c0 : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Bd + i * 32 * ROWF), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Bd + i * RA * ROWF), 16, 0, 0);
     }
   };
 
@@ -173,11 +217,22 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const BfLaunch L) {
   int issued = it0;
   auto issue_next = [&]() {
     if (issued < it1) {
-      if (issued == it0) {
-        setup_tap(tp);
-      } else if (++kc == kch) {
-        kc = 0;
-        setup_tap(++tp);
+      if (FAST) {
+        if (issued == it0) {
+          setup_seg(tp, kc);
+        } else if (++kc == kch) {
+          kc = 0;
+          setup_seg(++tp, 0);
+        } else if (kc == kch0) {
+          setup_seg(tp, kc);     // second concatenated source starts
+        }
+      } else {
+        if (issued == it0) {
+          setup_tap(tp);
+        } else if (++kc == kch) {
+          kc = 0;
+          setup_tap(++tp);
+        }
       }
       issue(kc * BKE, (issued - it0) % NBUF);
     }
@@ -192,8 +247,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const BfLaunch L) {
     if (younger >= 2) wait_vmcnt_bf<2 * G>();
     else if (younger == 1) wait_vmcnt_bf<G>();
     else wait_vmcnt_bf<0>();
-    __builtin_amdgcn_s_barrier();
-    issue_next();
+    __builtin_amdgcn_s_barrier();   // tile `it` visible to all waves; ring slot of tile it-1 is free again
     const float* Ab = As + buf * A_TILE + (wm * TM * 32 + l31) * ROWF;
     const float* Bb = Bs + buf * B_TILE + (wn * TN * 32 + l31) * ROWF;
 #pragma unroll
@@ -210,6 +264,9 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const BfLaunch L) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
                                                               __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+      // the DMA of K-step it+PD is issued in the shadow of the first MFMA group (the matrix pipe runs them
+      // asynchronously), not between the barrier and the first fragment reads
+      if (kg == 0) issue_next();
     }
   }
 
@@ -289,43 +346,47 @@ static int bf_validate(const sdm_igemm_desc* d, int out_f32) {
   return SDM_OK;
 }
 
-// tile / split-K choice: 128x128 tiles once they give most CUs a workgroup; else 64x64 tiles with enough K slices to
-// put ~2 workgroups on every CU while each still walks >= 4 K-steps.
-static void bf_plan(const sdm_igemm_desc* d, int* big, int* splitk, size_t* ws_need) {
-  static const char* force = getenv("SDM_BF16_FORCE");   // "big,splitk" tuning override
+// Tile configurations.  Measured on MI355X (profiles/r01_bf16_probe.txt): the contraction saturates near 770 TFLOP/s
+// -- operand movement L2 -> LDS (64 flop per tile byte at 128x128) and LDS fragment reads (one ds_read_b128 per
+// MFMA) run close to their limits together -- and what matters most below that is co-residency: two workgroups per CU
+// hide each other's DMA latency (ring 2, 64 KB: 1.3-1.5x over ring 3 with one workgroup).  A 256x128 / 8-wave tile
+// measured the same as two 128x128 workgroups, so it is not instantiated.
+//   cfg 0: 128x128, 4 waves (2x2), ring 2 (64 KB): two workgroups per CU
+//   cfg 1:  64x64,  4 waves (2x2), ring 3 (48 KB): three workgroups per CU; small problems, with split-K
+struct BfCfg { int bm, bn; };
+static const BfCfg kBfCfgs[2] = {{128, 128}, {64, 64}};
+
+static void bf_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* ws_need) {
+  static const char* force = getenv("SDM_BF16_FORCE");   // "cfg,splitk" tuning override
   const long ph = (long)d->nphase * d->batch;
   int maxtaps = 0;
   for (int p = 0; p < d->nphase; ++p) maxtaps = d->ntaps[p] > maxtaps ? d->ntaps[p] : maxtaps;
   const int T = maxtaps * cdiv(d->K, BKE);
   const long t128 = (long)cdiv(d->M, 128) * cdiv(d->N, 128) * ph;
   const long t64 = (long)cdiv(d->M, 64) * cdiv(d->N, 64) * ph;
-  int b = t128 >= 160 ? 1 : 0, sk = 1;
-  if (!b && t64 < 512) {
+  int c = t128 >= 320 ? 0 : 1, sk = 1;
+  if (c == 1 && t64 < 512) {
     sk = (int)((512 + t64 - 1) / t64);
     if (sk > T / 4) sk = T / 4;
     if (sk > 64) sk = 64;
     if (sk < 1) sk = 1;
   }
   if (force) {
-    int fb = 0, fs = 1;
-    if (sscanf(force, "%d,%d", &fb, &fs) == 2) { b = fb ? 1 : 0; sk = fs < 1 ? 1 : (fs > T ? T : fs); }
+    int fc = 0, fs = 1;
+    if (sscanf(force, "%d,%d", &fc, &fs) == 2 && fc >= 0 && fc <= 1) { c = fc; sk = fs < 1 ? 1 : (fs > T ? T : fs); }
   }
-  if (d->batch > 1 || d->nphase > 1) {
-    // split-K scratch is indexed [out row][N] of ONE problem: batched / multi-phase launches share out rows only when
-    // phases interleave into one output (conv-transpose) -- allowed -- but never across batch entries
-    if (d->batch > 1) sk = 1;
-  }
-  *big = b;
+  if (d->batch > 1) sk = 1;     // split-K scratch is indexed [out row][N] of one problem
+  *cfg = c;
   *splitk = sk;
   const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
   *ws_need = sk > 1 ? (size_t)out_rows * d->N * sizeof(float) : 0;
 }
 
-template <int BM, int BN, int NBUF>
+template <int BM, int BN, int WM, int WN, int NBUF, bool FAST>
 static int launch_bf(const BfLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = (size_t)NBUF * (BM + BN) * ROWF * sizeof(float) + BM * sizeof(long long) + 3 * SDM_MAX_TAPS * sizeof(int);
   static bool attr_set = false;
-  auto kern = igemm_bf16_kernel<BM, BN, NBUF>;
+  auto kern = igemm_bf16_kernel<BM, BN, WM, WN, NBUF, FAST>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
@@ -339,8 +400,8 @@ static int launch_bf(const BfLaunch& L, int ntm, hipStream_t st) {
     sdm_prof_shape(L.d.M, L.d.N, L.d.K, (int)taps, L.splitk, 2.0 * L.d.batch * (in_b + w_b + out_b));
   }
   sdm_prof_pre(st);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, L);
-  sdm_prof_post(st, BM == 128 ? 0 : 1, 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, L);
+  sdm_prof_post(st, BM >= 128 ? 0 : 1, 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
   SDM_CHECK_LAUNCH("igemm_bf16");
   return SDM_OK;
 }
@@ -360,27 +421,27 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
   BfLaunch L;
   L.d = *d;
   L.out_f32 = out_f32 ? 1 : 0;
-  int big;
+  int cfg;
   size_t need;
-  bf_plan(d, &big, &L.splitk, &need);
+  bf_plan(d, &cfg, &L.splitk, &need);
   if (L.splitk > 1 && (d->ws == nullptr || d->ws_bytes < need)) L.splitk = 1;
   L.kchunks = cdiv(d->K, BKE);
-  const int bm = big ? 128 : 64;
+  const int bm = kBfCfgs[cfg].bm, bn = kBfCfgs[cfg].bn;
   const int ntm = cdiv(d->M, bm);
-  L.ntn = cdiv(d->N, bm);
+  L.ntn = cdiv(d->N, bn);
   {
     int taps_all = 0;
     for (int ph = 0; ph < d->nphase; ++ph) taps_all += d->ntaps[ph];
     const long c = cdiv((long)ntm * L.ntn, 8);
-    const double a_tile = (double)bm * d->K, b_tile = (double)bm * d->K * taps_all;
+    const double a_tile = (double)bm * d->K, b_tile = (double)bn * d->K * taps_all;
     const double nfast = (double)cdiv(c, L.ntn) * a_tile + (double)(c < L.ntn ? c : L.ntn) * b_tile;
     const double mfast = (double)(c < ntm ? c : ntm) * a_tile + (double)cdiv(c, ntm) * b_tile;
     L.mfast = mfast < nfast ? 1 : 0;
   }
-  static const char* nb = getenv("SDM_BF16_NBUF");
-  const bool nb4 = nb && nb[0] == '4';
-  if (big) rc = nb4 ? launch_bf<128, 128, 4>(L, ntm, st) : launch_bf<128, 128, 3>(L, ntm, st);
-  else rc = nb4 ? launch_bf<64, 64, 4>(L, ntm, st) : launch_bf<64, 64, 3>(L, ntm, st);
+  static const char* nofast = getenv("SDM_BF16_FAST");
+  const bool fast = d->K % BKE == 0 && (d->a.p1 == nullptr || d->a.csplit % BKE == 0) && !(nofast && nofast[0] == '0');
+  if (cfg == 0) rc = fast ? launch_bf<128, 128, 2, 2, 2, true>(L, ntm, st) : launch_bf<128, 128, 2, 2, 2, false>(L, ntm, st);
+  else rc = fast ? launch_bf<64, 64, 2, 2, 3, true>(L, ntm, st) : launch_bf<64, 64, 2, 2, 3, false>(L, ntm, st);
   if (rc != SDM_OK) return rc;
   if (L.splitk > 1) {
     const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;

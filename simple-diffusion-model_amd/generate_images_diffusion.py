@@ -31,6 +31,8 @@ _FLAGS = [
     (("-l", "--labels"), dict(nargs="*", type=float, default=None, help="Conditional labels.")),
     # extension (not in the reference): classifier-free guidance weight; omit for the reference behaviour
     (("--cfg_scale",), dict(type=float, default=None, help="Classifier-free guidance weight w (conditional models).")),
+    # extension (not in the reference): bf16 storage of activations / contraction weights in the U-Net forward
+    (("--bf16",), dict(action="store_true", help="Run the U-Net in bf16 storage (fp32 accumulation, sampler in fp32).")),
 ]
 
 _UNET_KEYS = dict(in_channel="in_channel", out_channel="out_channel", num_layers="num_layers",
@@ -106,6 +108,8 @@ def generate_images_diffusion(raw_args=None, log=print, cond_img=None, save_loca
         if not ok:
             raise Exception("Failed to load model!")
         net.load_state_dict(ckpt["model"])
+        if args["bf16"]:
+            net.set_inference_dtype(torch.bfloat16)
         common = dict(diffusion_net=net, noise_degradation=schedule, x_t=x_t, min_noise=md["min_noise"],
                       max_noise=md["max_noise"], cond_img=cond_img, labels_tensor=labels, device=dev, log=log,
                       cfg_scale=args["cfg_scale"] if labels is not None else None)

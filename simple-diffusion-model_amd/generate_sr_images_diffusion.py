@@ -29,6 +29,8 @@ _FLAGS = [
     (("-l", "--labels"), dict(nargs="*", type=float, default=None, help="Labels Conditional e.g One-hot encoding.")),
     (("--lr_img_path",), dict(type=pathlib.Path, default=None, help="File path to image be upsampled.")),
     (("-T", "--max_T"), dict(type=int, default=1_000, help="Max T value for noise scheduling (ensembles).")),
+    # extension (not in the reference): bf16 storage of activations / contraction weights in the U-Net forward
+    (("--bf16",), dict(action="store_true", help="Run the U-Net in bf16 storage (fp32 accumulation, sampler in fp32).")),
 ]
 
 
@@ -96,6 +98,8 @@ def generate_sr_images_diffusion(raw_args=None, lr_img=None, log=print, save_loc
         if not ok:
             raise Exception("Failed to load model!")
         net.load_state_dict(ckpt["model"])
+        if args["bf16"]:
+            net.set_inference_dtype(torch.bfloat16)
         delta = cold_diffusion_sampling(diffusion_net=net, noise_degradation=schedule, x_t=x_t, noise=noise,
                                         min_noise=md["min_noise"], max_noise=md["max_noise"], cond_img=cond,
                                         labels_tensor=labels, skip_step_size=args["cold_step_size"], device=dev, log=log)
