@@ -30,6 +30,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) {   // round to nearest even (v_
 struct BfLaunch {
   sdm_igemm_desc d;
   int splitk, ntn, kchunks, mfast, out_f32;
+  int vec_epi;   // 4-column vector epilogue allowed (N % 4 == 0, 8-byte aligned output / residual rows, 16-byte bias)
 };
 
 __device__ float g_zero_chunk_bf[4];
@@ -276,6 +277,56 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
   bf16_t* out16 = (bf16_t*)d.out;
   const bf16_t* res16 = (const bf16_t*)d.res;
   const bf16_t* res216 = (const bf16_t*)d.res2;
+  if (L.splitk == 1 && L.vec_epi) {
+    // Staged through LDS: the accumulator layout gives a lane ONE column and 16 scattered rows of a 32x32 tile, i.e.
+    // 2-byte stores; the ring (no longer needed) is reused as an fp32 [BM][BN] tile so that every lane finishes 4
+    // consecutive columns and stores 8 bytes (16 for fp32 scores), rows fully coalesced.
+    static_assert((size_t)BM * BN <= (size_t)NBUF * (BM + BN) * ROWF, "output tile must fit in the ring");
+    __syncthreads();                       // every wave is done with the last K-step's fragments
+    float* Ct = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          Ct[row * BN + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];
+        }
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+#pragma unroll 2
+    for (int e = tid; e < BM * C4; e += NT) {
+      const int row = e / C4, c4 = (e - row * C4) * 4;
+      const int col = n0 + c4;
+      const long long orow = s_orow[row];
+      if (orow < 0 || col >= N) continue;
+      f32x4 v = *(const f32x4*)(Ct + row * BN + c4);
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (d.bias) bv = *(const f32x4*)(d.bias + col);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = sdm_act(v[q] * d.alpha + bv[q], d.act);
+      if (res16) {
+        const u16x4 rv = *(const u16x4*)(res16 + rbo + orow * d.ldres + col);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += bf2f(rv[q]);
+      }
+      if (res216) {
+        const u16x4 rv = *(const u16x4*)(res216 + orow * d.ldres2 + col);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += bf2f(rv[q]);
+      }
+      if (L.out_f32) {
+        *(f32x4*)(d.out + obo + orow * d.ldo + col) = v;
+      } else {
+        u16x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = f2bf(v[q]);
+        *(u16x4*)(out16 + obo + orow * d.ldo + col) = o;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -426,6 +477,15 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
   bf_plan(d, &cfg, &L.splitk, &need);
   if (L.splitk > 1 && (d->ws == nullptr || d->ws_bytes < need)) L.splitk = 1;
   L.kchunks = cdiv(d->K, BKE);
+  {
+    const size_t esz = out_f32 ? 4 : 2;
+    auto al = [](const void* q, size_t a) { return (((uintptr_t)q) & (a - 1)) == 0; };
+    static const char* noepi = getenv("SDM_BF16_VEC_EPI");
+    L.vec_epi = d->N % 4 == 0 && al(d->out, 4 * esz) && d->ldo % 4 == 0 && d->o_bs0 % 4 == 0 && d->o_bs1 % 4 == 0 &&
+                (d->bias == nullptr || al(d->bias, 16)) &&
+                (d->res == nullptr || (al(d->res, 8) && d->ldres % 4 == 0 && d->r_bs0 % 4 == 0 && d->r_bs1 % 4 == 0)) &&
+                (d->res2 == nullptr || (al(d->res2, 8) && d->ldres2 % 4 == 0)) && !(noepi && noepi[0] == '0');
+  }
   const int bm = kBfCfgs[cfg].bm, bn = kBfCfgs[cfg].bn;
   const int ntm = cdiv(d->M, bm);
   L.ntn = cdiv(d->N, bn);

@@ -42,10 +42,10 @@ print(json.dumps(res))
 
 def conv():
     names = [s[0] for s in SHAPES]
-    print("force  -    " + "  ".join(f"{n:>15s}" for n in names))
-    for force in ("0,1", "1,1", "1,4", "auto"):
-        for nb in ("1",):
-            env = dict(os.environ)
+    print("force  vepi " + "  ".join(f"{n:>15s}" for n in names))
+    for force in ("0,1", "1,1", "auto"):
+        for nb in ("0", "1"):
+            env = dict(os.environ, SDM_BF16_VEC_EPI=nb)
             if force != "auto":
                 env["SDM_BF16_FORCE"] = force
             r = subprocess.run([sys.executable, "-c", CHILD % (PKG, SHAPES)], env=env, capture_output=True, text=True)
