@@ -48,6 +48,11 @@ const char* sdm_last_error(void);
 int sdm_device_info(int* out4);
 /* sizeof the ABI structs (0 igemm desc, 1 wgrad desc, 2 rows, 3 linear job, 4 adam job) so a binding can assert its layout */
 size_t sdm_struct_size(int which);
+/* Stream ordering without host work: everything enqueued on `from` so far happens-before what is enqueued on `to`
+ * after this call (hipEventRecord on `from` + hipStreamWaitEvent on `to`, events from a library-owned ring; legal
+ * under stream capture, where it makes `to` join the capture).  The weight-gradient side stream forks and joins
+ * the main stream with it ~70 times per training step. */
+int sdm_stream_order(sdm_stream_t from, sdm_stream_t to);
 
 /* Per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg; not capturable, so
  * keep it off inside hipGraph capture).  Classes: 0 igemm 128x128, 1 igemm 64x64, 2 igemm 32x128,

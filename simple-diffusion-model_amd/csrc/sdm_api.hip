@@ -30,6 +30,30 @@ extern "C" int sdm_device_info(int* out4) {
 
 // sizes of the ABI structs, so a binding can assert its own layout (0: igemm desc, 1: wgrad desc, 2: rows,
 // 3: linear job, 4: adam job)
+// ring of timing-free events for sdm_stream_order (a wait captures the record that precedes it, so re-recording an
+// event later does not disturb earlier waits)
+#define SDM_ORDER_EVENTS 256
+static hipEvent_t g_order_ev[SDM_ORDER_EVENTS];
+static int g_order_next = -1;
+static int g_order_dev = -1;
+
+extern "C" int sdm_stream_order(sdm_stream_t from, sdm_stream_t to) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return sdm_set_error(SDM_ERR_LAUNCH, "stream_order: hipGetDevice failed");
+  if (g_order_next < 0 || dev != g_order_dev) {      // (re)build the ring on the current device
+    for (int i = 0; i < SDM_ORDER_EVENTS; ++i)
+      if (hipEventCreateWithFlags(&g_order_ev[i], hipEventDisableTiming) != hipSuccess)
+        return sdm_set_error(SDM_ERR_LAUNCH, "stream_order: hipEventCreate failed");
+    g_order_next = 0;
+    g_order_dev = dev;
+  }
+  hipEvent_t ev = g_order_ev[g_order_next];
+  g_order_next = (g_order_next + 1) % SDM_ORDER_EVENTS;
+  if (hipEventRecord(ev, (hipStream_t)from) != hipSuccess) return sdm_set_error(SDM_ERR_LAUNCH, "stream_order: record failed");
+  if (hipStreamWaitEvent((hipStream_t)to, ev, 0) != hipSuccess) return sdm_set_error(SDM_ERR_LAUNCH, "stream_order: wait failed");
+  return SDM_OK;
+}
+
 extern "C" size_t sdm_struct_size(int which) {
   switch (which) {
     case 0: return sizeof(sdm_igemm_desc);

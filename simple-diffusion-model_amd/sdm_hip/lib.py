@@ -82,6 +82,7 @@ _PROTOS = {
     "sdm_last_error": (C.c_char_p, []),
     "sdm_device_info": (C.c_int, [C.POINTER(C.c_int)]),
     "sdm_struct_size": (_sz, [_i]),
+    "sdm_stream_order": (_i, [fp, fp]),
     "sdm_prof_begin": (_i, [_i]),
     "sdm_prof_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sdm_igemm": (_i, [C.POINTER(IgemmDesc), fp]),

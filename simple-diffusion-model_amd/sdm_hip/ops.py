@@ -16,10 +16,29 @@ _raw_stream = torch._C._cuda_getCurrentRawStream
 _cur_device = torch._C._cuda_getDevice
 
 
+_override = [None]      # raw stream that launches go to inside a _SideStream.fork() block
+
+
 def _stream():
     # torch's current stream on the current device as a raw hipStream_t (the C accessors: the Python wrapper
     # torch.cuda.current_stream() costs ~7 us, which at ~300 launches per step was a quarter of the host time)
-    return _raw_stream(_cur_device())
+    o = _override[0]
+    return o if o is not None else _raw_stream(_cur_device())
+
+
+class _Fork:
+    """`with` block whose launches go to the given raw stream (no torch stream switch: nothing inside allocates)."""
+    __slots__ = ("raw",)
+
+    def __init__(self, raw):
+        self.raw = raw
+
+    def __enter__(self):
+        _override[0] = self.raw
+
+    def __exit__(self, *exc):
+        _override[0] = None
+        return False
 
 
 def _p(t):
@@ -101,16 +120,16 @@ class _SideStream:
         """Tensors read on the side stream are kept referenced until join(): their memory cannot be handed out again
         (on the compute stream) before the side stream is done with them -- also valid under hipGraph capture."""
         dev = tensors[0].device
-        side = self.stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
+        side = self.stream(dev).cuda_stream
+        lib.call("sdm_stream_order", _raw_stream(dev.index), side)       # side waits for what main has enqueued so far
         self.keep.extend(t for t in tensors if t is not None)
         self.dirty = True
-        return torch.cuda.stream(side)
+        return _Fork(side)
 
     def join(self):
         if self.dirty:
             for dev, side in self.streams.items():
-                torch.cuda.current_stream(dev).wait_stream(side)
+                lib.call("sdm_stream_order", side.cuda_stream, _raw_stream(dev.index))
             self.dirty = False
         self.keep.clear()
 
@@ -148,10 +167,30 @@ _CT_1D = {0: [(1, 0), (3, -1)], 1: [(0, 1), (2, 0)]}      # (k, d)
 _S2D_1D = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}
 
 
-def _set_taps(d, phase, taps):
-    d.ntaps[phase] = len(taps)
-    for i, (dy, dx, w) in enumerate(taps):
-        d.tap_dy[phase][i], d.tap_dx[phase][i], d.tap_w[phase][i] = dy, dx, w
+def _cols(taps):
+    """(n, [dy...], [dx...], [w...]) -- column form of a static tap table, assigned to the descriptor by slices."""
+    return (len(taps), [t[0] for t in taps], [t[1] for t in taps], [t[2] for t in taps])
+
+
+def _set_taps(d, phase, cols):
+    n, dys, dxs, ws = cols if isinstance(cols, tuple) else _cols(cols)
+    d.ntaps[phase] = n
+    d.tap_dy[phase][:n] = dys
+    d.tap_dx[phase][:n] = dxs
+    d.tap_w[phase][:n] = ws
+
+
+_C3_COLS = _cols(_C3)
+_C3_NEG_COLS = _cols([(-dy, -dx, wi) for (dy, dx, wi) in _C3])
+_CT_PHASE_COLS = {(a, b): _cols([(dy, dx, ky * 4 + kx) for (ky, dy) in _CT_1D[a] for (kx, dx) in _CT_1D[b]])
+                  for a in (0, 1) for b in (0, 1)}
+_S2D_PHASE_COLS = {(a, b): _cols([(dy, dx, ky * 3 + kx) for (ky, dy) in _S2D_1D[a] for (kx, dx) in _S2D_1D[b]])
+                   for a in (0, 1) for b in (0, 1)}
+_CT_DGRAD_COLS = _cols([(ky - 1, kx - 1, ky * 4 + kx) for ky in range(4) for kx in range(4)])
+_WG_CT = [(ky - 1, kx - 1, 0, 0, ky * 4 + kx) for ky in range(4) for kx in range(4)]
+_WG_C3 = [(0, 0, ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+_WG_CT_COLS = tuple([t[i] for t in _WG_CT] for i in range(5))
+_WG_C3_COLS = tuple([t[i] for t in _WG_C3] for i in range(5))
 
 
 BF16 = torch.bfloat16
@@ -214,13 +253,13 @@ def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False):
         for a in (0, 1):
             for b in (0, 1):
                 ph = a * 2 + b
-                _set_taps(d, ph, [(dy, dx, ky * 4 + kx) for (ky, dy) in _CT_1D[a] for (kx, dx) in _CT_1D[b]])
+                _set_taps(d, ph, _CT_PHASE_COLS[(a, b)])
                 d.ph_oy[ph], d.ph_ox[ph] = a, b
     else:
         s = 1 if kind == "c3s1" else 2
         d = _base_desc(x.n * ho * wo, cout, cin)
         d.Ht, d.Wt, d.sstride = ho, wo, s
-        _set_taps(d, 0, _C3)
+        _set_taps(d, 0, _C3_COLS)
     fill_rows(d.a, x)
     d.b, d.ldb, d.b_tap_stride, d.b_kmajor = _p(wt), cin, cout * cin, 0
     d.Ho, d.Wo = ho, wo
@@ -241,7 +280,7 @@ def conv_dgrad(g, g_hw, wt, kind, x_hw, n, res=None, res2=None, dact_z=None, dac
     if kind == "c3s1":
         d = _base_desc(n * h * w, cin, cout)
         d.Ht, d.Wt = h, w
-        _set_taps(d, 0, [(-dy, -dx, wi) for (dy, dx, wi) in _C3])
+        _set_taps(d, 0, _C3_NEG_COLS)
     elif kind == "c3s2":
         ht, wt_ = (h + 1) // 2, (w + 1) // 2
         d = _base_desc(n * ht * wt_, cin, cout)
@@ -249,12 +288,12 @@ def conv_dgrad(g, g_hw, wt, kind, x_hw, n, res=None, res2=None, dact_z=None, dac
         for a in (0, 1):
             for b in (0, 1):
                 ph = a * 2 + b
-                _set_taps(d, ph, [(dy, dx, ky * 3 + kx) for (ky, dy) in _S2D_1D[a] for (kx, dx) in _S2D_1D[b]])
+                _set_taps(d, ph, _S2D_PHASE_COLS[(a, b)])
                 d.ph_oy[ph], d.ph_ox[ph] = a, b
     elif kind == "ct4":
         d = _base_desc(n * h * w, cin, cout)
         d.Ht, d.Wt, d.sstride = h, w, 2
-        _set_taps(d, 0, [(ky - 1, kx - 1, ky * 4 + kx) for ky in range(4) for kx in range(4)])
+        _set_taps(d, 0, _CT_DGRAD_COLS)
     else:
         raise ValueError(kind)
     fill_rows(d.a, ga)
@@ -286,15 +325,14 @@ def conv_wgrad(g, g_hw, x, kind, dwt, accumulate=2, dbias=None):
     if kind == "ct4":
         d.Hk, d.Wk = x.h, x.w
         d.g_stride, d.x_stride = 2, 1
-        taps = [(ky - 1, kx - 1, 0, 0, ky * 4 + kx) for ky in range(4) for kx in range(4)]
+        cols, nt = _WG_CT_COLS, 16
     else:
         s = 1 if kind == "c3s1" else 2
         d.Hk, d.Wk = ho, wo
         d.g_stride, d.x_stride = 1, s
-        taps = [(0, 0, ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
-    d.ntaps = len(taps)
-    for i, (gdy, gdx, xdy, xdx, wi) in enumerate(taps):
-        d.g_dy[i], d.g_dx[i], d.x_dy[i], d.x_dx[i], d.tap_w[i] = gdy, gdx, xdy, xdx, wi
+        cols, nt = _WG_C3_COLS, 9
+    d.ntaps = nt
+    d.g_dy[:nt], d.g_dx[:nt], d.x_dy[:nt], d.x_dx[:nt], d.tap_w[:nt] = cols
     d.dw, d.ldw, d.w_tap_stride = _p(dwt), cin, cout * cin
     d.alpha, d.accumulate = 1.0, int(accumulate)
     if dbias is not None and kind != "ct4":
