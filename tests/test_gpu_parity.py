@@ -266,6 +266,18 @@ def test_embedding_golden(dev, L):
         assert rel(y, T(b[f"{tag}/y"])) < 2e-5, (tag, rel(y, T(b[f"{tag}/y"])))
 
 
+def test_embedding_large_batch_path(dev, L):
+    """From 32 rows on the embedding MLPs run on the matrix-core contraction instead of the GEMV kernel: same numbers
+    as the small-batch path evaluated 16 rows at a time (which test_embedding_golden pins to the reference)."""
+    torch.manual_seed(4)
+    m = L.ConditionalEmbedding(64, 8).cuda()
+    t = torch.randint(1, 1000, (80,), device="cuda")
+    c = torch.randn(80, 8, device="cuda")
+    big = m(t, c)
+    small = torch.cat([m(t[i:i + 16], c[i:i + 16]) for i in range(0, 80, 16)], dim=0)
+    assert rel(big, small) < 2e-6, rel(big, small)
+
+
 # ------------------------------------------------------------------------------------------------
 # whole-model goldens (reference outputs) and gradients
 # ------------------------------------------------------------------------------------------------
