@@ -201,7 +201,8 @@ int sdm_gn_affine(const float* y, int64_t ldy, int images, int HW, int C, int gr
                   const float* gamma, const float* beta, const float* mod, int mod_nstride,
                   float* scale, float* shift, float* mean, float* rstd, sdm_stream_t s);
 
-/* out[r][c] = scale[n][c]*y[r][c] + shift[n][c] + cat(x0,x1)[r][c]   (ResidualBlock tail, custom_layers.py:284-286) */
+/* out[r][c] = scale[n][c]*y[r][c] + shift[n][c] + cat(x0,x1)[r][c]   (ResidualBlock tail, custom_layers.py:284-286);
+ * x0 NULL = affine only (materialises a conv input whose GroupNorm+AdaGN affine is pending). */
 int sdm_affine_residual(const float* y, int64_t ldy, const float* scale, const float* shift, int aff_nstride,
                         const float* x0, int64_t ldx0, const float* x1, int64_t ldx1, int csplit,
                         float* out, int64_t ldo, int images, int HW, int C, sdm_stream_t s);

@@ -431,8 +431,8 @@ __global__ __launch_bounds__(256) void affine_residual_kernel(const float* __res
         const f32x4 b = *(const f32x4*)(shift + (long long)n * ans + c);
         v = v * a + b;
       }
-      const f32x4 xv = (c < csplit) ? *(const f32x4*)(x0 + r * ldx0 + c) : *(const f32x4*)(x1 + r * ldx1 + (c - csplit));
-      *(f32x4*)(out + r * ldo + c) = v + xv;
+      if (x0) v += (c < csplit) ? *(const f32x4*)(x0 + r * ldx0 + c) : *(const f32x4*)(x1 + r * ldx1 + (c - csplit));
+      *(f32x4*)(out + r * ldo + c) = v;
     }
   } else {
     const long long total = rows * C;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void affine_residual_kernel(const float* __res
       const int n = (int)(r / HW);
       float v = y[r * ldy + c];
       if (scale) v = v * scale[(long long)n * ans + c] + shift[(long long)n * ans + c];
-      v += (c < csplit) ? x0[r * ldx0 + c] : x1[r * ldx1 + (c - csplit)];
+      if (x0) v += (c < csplit) ? x0[r * ldx0 + c] : x1[r * ldx1 + (c - csplit)];
       out[r * ldo + c] = v;
     }
   }
@@ -451,11 +451,12 @@ __global__ __launch_bounds__(256) void affine_residual_kernel(const float* __res
 extern "C" int sdm_affine_residual(const float* y, int64_t ldy, const float* scale, const float* shift, int aff_nstride,
                                    const float* x0, int64_t ldx0, const float* x1, int64_t ldx1, int csplit, float* out,
                                    int64_t ldo, int images, int HW, int C, sdm_stream_t s) {
-  SDM_CHECK_ARG(y && x0 && out && images > 0 && HW > 0 && C > 0, "affine_residual: bad args");
-  SDM_CHECK_ARG(x1 != nullptr || csplit >= C, "affine_residual: csplit < C without second source");
+  SDM_CHECK_ARG(y && out && images > 0 && HW > 0 && C > 0, "affine_residual: bad args");
+  SDM_CHECK_ARG(x0 == nullptr || x1 != nullptr || csplit >= C, "affine_residual: csplit < C without second source");
   const long long rows = (long long)images * HW;
-  const int vec = (C % 4 == 0) && (csplit % 4 == 0) && ldy % 4 == 0 && ldx0 % 4 == 0 && (x1 == nullptr || ldx1 % 4 == 0) &&
-                  ldo % 4 == 0 && aff_nstride % 4 == 0 && aligned16(y) && aligned16(x0) && aligned16(out) &&
+  const int vec = (C % 4 == 0) && (x0 == nullptr || csplit % 4 == 0) && ldy % 4 == 0 && ldx0 % 4 == 0 &&
+                  (x1 == nullptr || ldx1 % 4 == 0) && ldo % 4 == 0 && aff_nstride % 4 == 0 && aligned16(y) &&
+                  (x0 == nullptr || aligned16(x0)) && aligned16(out) &&
                   (x1 == nullptr || aligned16(x1)) && (scale == nullptr || (aligned16(scale) && aligned16(shift)));
   long long work = rows * (vec ? C / 4 : C);
   int grid = (int)((work + 255) / 256);

@@ -22,6 +22,7 @@ in training mode, leaves a record in ``ctx.rec[self]`` that its ``backward`` con
 (NCHW in/out) exists for standalone use of a block and for block-level tests.
 """
 import math
+import os
 from enum import Enum
 
 import torch
@@ -48,6 +49,9 @@ class RunCtx:
         self.mods = None      # {AdaGN: modulation rows} when the net evaluated all y_scale projections in one launch
         self.dmods = None     # {AdaGN: gradient rows} consumed by the batched y_scale data gradient
         self.bank = None      # the y_scale job tables this forward used (ops.LinearBank.tables())
+
+
+MATERIALIZE_TRAIN = [os.environ.get("SDM_TRAIN_MATERIALIZE", "1") != "0"]
 
 
 def bf16_weight(mod, key, src_fn):
@@ -413,7 +417,10 @@ class ResidualBlock(nn.Module):
 
     def run(self, ctx, x, emb=None):
         y1, aff1 = self.conv_block_1.run(ctx, x, emb)
-        if ctx.bf16 and aff1 is not None:      # bf16 rows: the affine is materialised (the LDS-DMA tiles cannot apply it)
+        if (ctx.bf16 or (ctx.train and MATERIALIZE_TRAIN[0])) and aff1 is not None:
+            # the affine is materialised: the LDS-DMA tiles cannot apply it on the fly.  bf16 rows always; in training
+            # one extra pass buys the fast (LDS-DMA) kernels for this conv's forward AND its weight gradient, which
+            # would otherwise both run the register-staged affine-on-load variants
             x2 = ops.affine_residual(y1, aff1[0], aff1[1], None)
         else:
             x2 = y1 if aff1 is None else Act(y1.t, y1.n, y1.h, y1.w, scale=aff1[0], shift=aff1[1])

@@ -598,7 +598,7 @@ def gn_affine(y, gamma, beta, mod, groups=32, eps=1e-5):
 
 
 def affine_residual(y, scale, shift, x):
-    """out = scale*y + shift + cat(x.t, x.t2)  (plain Act).  bf16 rows: x may be None (affine only)."""
+    """out = scale*y + shift + cat(x.t, x.t2)  (plain Act); x None = affine only."""
     ans = 0 if (scale is None or scale.shape[0] == 1) else scale.stride(0)
     if y.t.dtype == BF16:
         out = torch.empty((y.rows, y.c), dtype=BF16, device=y.t.device)
@@ -609,9 +609,11 @@ def affine_residual(y, scale, shift, x):
                  x.c1 if x1 is not None else (1 << 30), _p(out), out.stride(0), y.n, y.h * y.w, y.c, _stream())
         return Act(out, y.n, y.h, y.w)
     out = torch.empty((y.rows, y.c), dtype=torch.float32, device=y.t.device)
-    lib.call("sdm_affine_residual", _p(y.t), y.t.stride(0), _p(scale), _p(shift), ans, _p(x.t), x.t.stride(0), _p(x.t2),
-             x.t2.stride(0) if x.t2 is not None else 0, x.c1 if x.t2 is not None else (1 << 30), _p(out), out.stride(0),
-             y.n, y.h * y.w, y.c, _stream())
+    x0 = None if x is None else x.t
+    x1 = None if x is None else x.t2
+    lib.call("sdm_affine_residual", _p(y.t), y.t.stride(0), _p(scale), _p(shift), ans, _p(x0),
+             x0.stride(0) if x0 is not None else 0, _p(x1), x1.stride(0) if x1 is not None else 0,
+             x.c1 if x1 is not None else (1 << 30), _p(out), out.stride(0), y.n, y.h * y.w, y.c, _stream())
     return Act(out, y.n, y.h, y.w)
 
 
