@@ -206,8 +206,16 @@ class U_Net(nn.Module):
         n, H, W = hin.n, hin.h, hin.w
         st = ops._stream()
         slab = self._edge_slab(dout.device)
-        ops.lib.call("sdm_head_conv_wgrad", hin.t.data_ptr(), dout.data_ptr(), head.grad_taps(grads[head.weight]).data_ptr(),
-                     grads[head.bias].data_ptr(), slab.data_ptr(), n, hin.c, H, W, self.out_channel, st)
+
+        def head_wgrad():
+            ops.lib.call("sdm_head_conv_wgrad", hin.t.data_ptr(), dout.data_ptr(),
+                         head.grad_taps(grads[head.weight]).data_ptr(), grads[head.bias].data_ptr(), slab.data_ptr(), n, hin.c,
+                         H, W, self.out_channel, ops._stream())
+        if ops.SIDE.enabled:           # edge weight gradients ride the side stream too (they share `slab`: same stream)
+            with ops.SIDE.fork(hin.t, dout):
+                head_wgrad()
+        else:
+            head_wgrad()
         dz = torch.empty_like(hin.t)
         ops.lib.call("sdm_head_conv_dgrad", dout.data_ptr(), head.taps().data_ptr(), dz.data_ptr(), hin.z.data_ptr(), n,
                      hin.c, H, W, self.out_channel, st)
@@ -235,8 +243,15 @@ class U_Net(nn.Module):
         dz = self.in_layer[1].backward(ctx, dz, grads)
         stem = self.in_layer[0].conv_layer.conv
         x = ctx.rec["x"]
-        ops.lib.call("sdm_stem_conv_wgrad", x.data_ptr(), dz.data_ptr(), stem.grad_taps(grads[stem.weight]).data_ptr(),
-                     grads[stem.bias].data_ptr(), slab.data_ptr(), x.shape[0], x.shape[1], x.shape[2], x.shape[3], stem.cout, st)
+        def stem_wgrad():
+            ops.lib.call("sdm_stem_conv_wgrad", x.data_ptr(), dz.data_ptr(), stem.grad_taps(grads[stem.weight]).data_ptr(),
+                         grads[stem.bias].data_ptr(), slab.data_ptr(), x.shape[0], x.shape[1], x.shape[2], x.shape[3],
+                         stem.cout, ops._stream())
+        if ops.SIDE.enabled:
+            with ops.SIDE.fork(x, dz):
+                stem_wgrad()
+        else:
+            stem_wgrad()
         hook("in_layer")
         if self.cond_emb is not None:
             if ctx.dmods is not None:

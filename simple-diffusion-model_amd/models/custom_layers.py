@@ -199,8 +199,12 @@ class AdaGN(nn.Module):
         dW, db = grads[self.y_scale.weight], grads[self.y_scale.bias]
         # weight/bias gradients now (the block's gradients must be complete when the block ends: DP buckets);
         # the embedding gradient of ALL projections is one batched launch at the end of the backward
-        ops.linear_small_bwd(dmod, ctx.emb, self.y_scale.weight, dx=None if batched else ctx.demb, dx_accumulate=True,
-                             dW=dW, db=db)
+        if batched and ops.SIDE.enabled:          # weight / bias gradient only: side stream
+            with ops.SIDE.fork(dmod, ctx.emb):
+                ops.linear_small_bwd(dmod, ctx.emb, self.y_scale.weight, dx=None, dW=dW, db=db)
+        else:
+            ops.linear_small_bwd(dmod, ctx.emb, self.y_scale.weight, dx=None if batched else ctx.demb, dx_accumulate=True,
+                                 dW=dW, db=db)
         return dz
 
     def forward(self, x, emb):

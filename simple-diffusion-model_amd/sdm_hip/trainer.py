@@ -153,6 +153,11 @@ class DiffusionTrainer:
                 work.wait()                                             # blocks the optimizer stream only
             j0, j1 = self.bucket_jobs[i]
             self.opt.step(j0, j1 - j0, grad_scale=1.0 / self.world, advance=False, hyper=getattr(self, "_hyper", None))
+            # the bucket's gradients are consumed: clear them here, on the optimizer stream, for the next backward
+            # (which accumulates) instead of a 0.5 GB memset at the head of the next step on the compute stream
+            s, e = self.reducer.buckets[i][0], self.reducer.buckets[i][1]
+            self.flat[s:e].zero_()
+            self._cleared += e - s
 
     def _body(self, x0, labels, eps, t, hyper=None):
         abar = self.schedule.alpha_bar_of(t)
@@ -164,7 +169,9 @@ class DiffusionTrainer:
             abar_c = self.schedule.alpha_bar_of(torch.full((x0.shape[0],), int(cond_t), dtype=torch.int64, device=self.dev))
             x_t = torch.cat((x_t, ops.q_sample(low, eps, abar_c)), dim=1)
             target = x0 - low
-        self.flat.zero_()                               # backward accumulates (split-K atomics, column sums)
+        if getattr(self, "_cleared", 0) != self.flat.numel():
+            self.flat.zero_()                           # first step, or the previous one did not finish: start clean
+        self._cleared = 0                               # backward accumulates (split-K atomics, column sums)
         self.reducer.begin_step()
         self._hyper = hyper
         self.net._block_done_hook = self._bucket_closed
