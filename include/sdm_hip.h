@@ -212,11 +212,13 @@ int sdm_affine_residual(const float* y, int64_t ldy, const float* scale, const f
  *   dz = silu'(z) * rstd*( dout*s*gamma - mean_g(dout*s*gamma) - xhat*mean_g(dout*s*gamma*xhat) )
  *   dmod[n][c]   = sum_hw dout*(xhat*gamma+beta+1)
  *   dgamma[c] += sum_{n,hw} dout*s*xhat ; dbeta[c] += sum_{n,hw} dout*s
- * ws: images*C*5 floats. */
+ * ws: images*C*2 floats of per-channel sums, ZERO on entry and zero again when the call has run (zero-filled-scratch
+ * contract, like the split-K workspace); coef: images*C*3 floats of scratch with no contract. */
 int sdm_gn_adagn_bwd(const float* dout, int64_t lddo, const float* y, int64_t ldy, const float* z, int64_t ldz,
                      int images, int HW, int C, int groups, const float* gamma, const float* beta,
                      const float* mod, int mod_nstride, const float* mean, const float* rstd,
-                     float* dz, int64_t lddz, float* dmod, float* dgamma, float* dbeta, float* ws, sdm_stream_t s);
+                     float* dz, int64_t lddz, float* dmod, float* dgamma, float* dbeta, float* ws, float* coef,
+                     sdm_stream_t s);
 
 /* Column softmax of attention scores (custom_layers.py:147: softmax(dim=1) = over QUERIES i for each key j).
  * scores [batch][S][lds] in place. */

@@ -468,7 +468,8 @@ extern "C" int sdm_affine_residual(const float* y, int64_t ldy, const float* sca
 }
 
 // --------------------------------------------------------------------------------------------
-// AdaGN backward (see header).  ws: [images][C][2] = (sum dout, sum dout*y)
+// AdaGN backward (see header).  ws: sums [images][C][2] = (sum dout, sum dout*y) -- zero on entry, zero again on
+// return (the coefficient pass clears what it consumed); coef: [images][3][C], no contract.
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const float* __restrict__ dout, long long lddo,
                                                           const float* __restrict__ y, long long ldy, int HW, int C,
@@ -490,9 +491,51 @@ __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const float* __restric
   }
 }
 
-// one block per (image, group): turns the sums into per-channel coefficients (k1,k2,k3) stored back into ws-like
-// coef[n][C][3], and emits dmod / dgamma / dbeta.
-__global__ __launch_bounds__(64) void gn_bwd_coef_kernel(const float* __restrict__ ws, int HW, int C, int groups,
+// float4 form (C % 4 == 0, C <= 1024, 16-byte aligned rows): a row of C channels takes C/4 lanes, the remaining
+// 256/(C/4) lane groups walk different rows; partials meet in LDS, one atomic pair per channel per workgroup.
+__global__ __launch_bounds__(256) void gn_bwd_sums_vec_kernel(const float* __restrict__ dout, long long lddo,
+                                                              const float* __restrict__ y, long long ldy, int HW, int C,
+                                                              int rows_per_block, float* __restrict__ ws) {
+  __shared__ float part[2][256][4];
+  const int n = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > HW) r1 = HW;
+  const int q = C >> 2;                  // lanes per row
+  const int rl = threadIdx.x / q, cl = threadIdx.x - rl * q;
+  const int RL = 256 / q;                // rows in flight
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  if (rl < RL) {
+    for (int r = r0 + rl; r < r1; r += RL) {
+      const long long row = (long long)n * HW + r;
+      const f32x4 d = *(const f32x4*)(dout + row * lddo + cl * 4);
+      const f32x4 yv = *(const f32x4*)(y + row * ldy + cl * 4);
+      s1 += d;
+      s2 += d * yv;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    part[0][threadIdx.x][k] = s1[k];
+    part[1][threadIdx.x][k] = s2[k];
+  }
+  __syncthreads();
+  // thread t < C finishes channel t: lane group cl = t/4, element t%4, summed over the RL row groups
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c >> 2, k = c & 3;
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < RL; ++j) {
+      a += part[0][j * q + g][k];
+      b += part[1][j * q + g][k];
+    }
+    atomicAdd(&ws[((long long)n * C + c) * 2 + 0], a);
+    atomicAdd(&ws[((long long)n * C + c) * 2 + 1], b);
+  }
+}
+
+// one block per (image, group): turns the sums into per-channel coefficients (k1,k2,k3) stored planar in
+// coef[n][3][C], emits dmod / dgamma / dbeta, and clears the sums it consumed.
+__global__ __launch_bounds__(64) void gn_bwd_coef_kernel(float* __restrict__ ws, int HW, int C, int groups,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mod, int mod_ns,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -517,14 +560,17 @@ __global__ __launch_bounds__(64) void gn_bwd_coef_kernel(const float* __restrict
   B /= cnt;
   for (int c = threadIdx.x; c < cpg; c += 64) {
     const int ch = g * cpg + c;
-    const float S1 = ws[((long long)n * C + ch) * 2], S2 = ws[((long long)n * C + ch) * 2 + 1];
+    float* sums = ws + ((long long)n * C + ch) * 2;
+    const float S1 = sums[0], S2 = sums[1];
+    sums[0] = 0.f;      // same thread read these two words in the first loop as well: nobody else touches them
+    sums[1] = 0.f;
     const float sm = mod ? mod[(long long)n * mod_ns + ch] : 1.f;
     const float ga = gamma[ch], be = beta[ch];
     const float xh = rs * (S2 - mu * S1);  // sum dout * xhat
-    float* k = coef + ((long long)n * C + ch) * 3;
+    float* k = coef + (long long)n * 3 * C + ch;
     k[0] = rs * sm * ga;
-    k[1] = -rs * rs * B;
-    k[2] = -rs * A + mu * rs * rs * B;
+    k[C] = -rs * rs * B;
+    k[2 * C] = -rs * A + mu * rs * rs * B;
     if (dmod) dmod[(long long)n * C + ch] = ga * xh + (mod ? (be + 1.f) : be) * S1;
     if (dgamma) atomicAdd(&dgamma[ch], sm * xh);
     if (dbeta) atomicAdd(&dbeta[ch], sm * S1);
@@ -535,14 +581,33 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ y, long long ldy,
                                                            const float* __restrict__ z, long long ldz,
                                                            const float* __restrict__ coef, float* __restrict__ dz,
-                                                           long long lddz, long long rows, int HW, int C) {
+                                                           long long lddz, long long rows, int HW, int C, int vec) {
+  if (vec) {
+    const int C4 = C >> 2;
+    const long long total = rows * C4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+      const long long r = e / C4;
+      const int c = (int)(e - r * C4) * 4;
+      const int n = (int)(r / HW);
+      const float* k = coef + (long long)n * 3 * C + c;
+      const f32x4 k0 = *(const f32x4*)k, k1 = *(const f32x4*)(k + C), k2 = *(const f32x4*)(k + 2 * C);
+      f32x4 v = k0 * *(const f32x4*)(dout + r * lddo + c) + k1 * *(const f32x4*)(y + r * ldy + c) + k2;
+      if (z) {
+        const f32x4 zv = *(const f32x4*)(z + r * ldz + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= sdm_dsilu(zv[i]);
+      }
+      *(f32x4*)(dz + r * lddz + c) = v;
+    }
+    return;
+  }
   const long long total = rows * C;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const long long r = e / C;
     const int c = (int)(e - r * C);
     const int n = (int)(r / HW);
-    const float* k = coef + ((long long)n * C + c) * 3;
-    float v = k[0] * dout[r * lddo + c] + k[1] * y[r * ldy + c] + k[2];
+    const float* k = coef + (long long)n * 3 * C + c;
+    float v = k[0] * dout[r * lddo + c] + k[C] * y[r * ldy + c] + k[2 * C];
     if (z) v *= sdm_dsilu(z[r * ldz + c]);
     dz[r * lddz + c] = v;
   }
@@ -551,25 +616,31 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 extern "C" int sdm_gn_adagn_bwd(const float* dout, int64_t lddo, const float* y, int64_t ldy, const float* z, int64_t ldz,
                                 int images, int HW, int C, int groups, const float* gamma, const float* beta,
                                 const float* mod, int mod_nstride, const float* mean, const float* rstd, float* dz,
-                                int64_t lddz, float* dmod, float* dgamma, float* dbeta, float* ws, sdm_stream_t s) {
-  SDM_CHECK_ARG(dout && y && gamma && beta && mean && rstd && dz && ws, "gn_adagn_bwd: null pointer");
+                                int64_t lddz, float* dmod, float* dgamma, float* dbeta, float* ws, float* coef,
+                                sdm_stream_t s) {
+  SDM_CHECK_ARG(dout && y && gamma && beta && mean && rstd && dz && ws && coef, "gn_adagn_bwd: null pointer");
   SDM_CHECK_ARG(images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_adagn_bwd: bad dims");
   hipStream_t st = (hipStream_t)s;
-  float* coef = ws + (size_t)images * C * 2;  // caller provides images*C*5 floats
-  SDM_MEMSET0(ws, (size_t)images * C * 2 * sizeof(float), st);
+  const bool vec = C % 4 == 0 && lddo % 4 == 0 && ldy % 4 == 0 && lddz % 4 == 0 && (z == nullptr || ldz % 4 == 0) &&
+                   aligned16(dout) && aligned16(y) && aligned16(dz) && (z == nullptr || aligned16(z)) && aligned16(coef);
   int rpb = (HW + 63) / 64;
   if (rpb < 8) rpb = 8;
-  hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(cdiv(HW, rpb), images), dim3(256), 0, st, dout, (long long)lddo, y,
-                     (long long)ldy, HW, C, rpb, ws);
+  if (vec && C <= 1024)
+    hipLaunchKernelGGL(gn_bwd_sums_vec_kernel, dim3(cdiv(HW, rpb), images), dim3(256), 0, st, dout, (long long)lddo, y,
+                       (long long)ldy, HW, C, rpb, ws);
+  else
+    hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(cdiv(HW, rpb), images), dim3(256), 0, st, dout, (long long)lddo, y,
+                       (long long)ldy, HW, C, rpb, ws);
   SDM_CHECK_LAUNCH("gn_bwd_sums");
   hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(images * groups), dim3(64), 0, st, ws, HW, C, groups, gamma, beta, mod,
                      mod_nstride, mean, rstd, coef, dmod, dgamma, dbeta);
   SDM_CHECK_LAUNCH("gn_bwd_coef");
   const long long rows = (long long)images * HW;
-  int grid = (int)((rows * C + 255) / 256);
+  const long long work = rows * (vec ? C / 4 : C);
+  int grid = (int)((work + 255) / 256);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, dout, (long long)lddo, y, (long long)ldy, z,
-                     (long long)ldz, coef, dz, (long long)lddz, rows, HW, C);
+                     (long long)ldz, coef, dz, (long long)lddz, rows, HW, C, vec ? 1 : 0);
   SDM_CHECK_LAUNCH("gn_bwd_apply");
   return SDM_OK;
 }

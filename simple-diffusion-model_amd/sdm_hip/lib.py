@@ -97,7 +97,7 @@ _PROTOS = {
     "sdm_gn_affine": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, fp, fp, fp, fp]),
     "sdm_affine_residual": (_i, [fp, _i64, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, _i, _i, _i, fp]),
     "sdm_gn_adagn_bwd": (_i, [fp, _i64, fp, _i64, fp, _i64, _i, _i, _i, _i, fp, fp, fp, _i, fp, fp, fp, _i64,
-                              fp, fp, fp, fp, fp]),
+                              fp, fp, fp, fp, fp, fp]),
     "sdm_col_softmax": (_i, [fp, _i, _i, _i64, fp]),
     "sdm_col_softmax_bwd": (_i, [fp, fp, _i, _i, _i64, _f, fp]),
     "sdm_sinusoid": (_i, [fp, fp, _i, _i, fp, fp]),

@@ -158,6 +158,7 @@ class _Workspace:
 
 
 WS = _Workspace()
+GNWS = _Workspace()     # scratch of sdm_gn_adagn_bwd (same zero-filled contract; separate so sizes do not interact)
 
 # ---- tap tables -----------------------------------------------------------------------------
 _C3 = [(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
@@ -624,11 +625,12 @@ def gn_adagn_bwd(dout, y, z, n, hw, gamma, beta, mod, mean, rstd, dgamma, dbeta,
     dz = torch.empty((n * hw, C_), dtype=torch.float32, device=dev)
     if dmod is None and mod is not None:
         dmod = torch.empty((n, C_), dtype=torch.float32, device=dev)
-    ws = torch.empty((n * C_ * 5,), dtype=torch.float32, device=dev)
+    ws = GNWS.get(n * C_ * 2 * 4, dev)         # persistent, zero-filled; the kernels leave it zero
+    coef = torch.empty((n * 3 * C_,), dtype=torch.float32, device=dev)
     mns = 0 if (mod is None or mod.shape[0] == 1) else mod.stride(0)
     lib.call("sdm_gn_adagn_bwd", _p(dout), dout.stride(0), _p(y), y.stride(0), _p(z), z.stride(0) if z is not None else 0,
              n, hw, C_, groups, _p(gamma), _p(beta), _p(mod), mns, _p(mean), _p(rstd), _p(dz), dz.stride(0), _p(dmod),
-             _p(dgamma), _p(dbeta), _p(ws), _stream())
+             _p(dgamma), _p(dbeta), _p(ws), _p(coef), _stream())
     return dz, dmod
 
 

@@ -36,6 +36,19 @@ def test_launch_functions_validate_arguments_without_a_gpu():
         lib.call("sdm_igemm", C.byref(d), None)
     with pytest.raises(lib.SdmError, match="col_softmax"):
         lib.call("sdm_col_softmax", None, 0, 0, 0, None)
+    # bf16 entry points: same descriptor, stricter alignment rules, checked before any launch
+    with pytest.raises(lib.SdmError, match="igemm_bf16"):
+        lib.call("sdm_igemm_bf16", C.byref(d), 0, None)
+    d.M, d.N, d.K, d.batch, d.bdiv, d.Ht, d.Wt, d.nphase = 64, 64, 36, 1, 1, 64, 1, 1      # K not a multiple of 8
+    d.ntaps[0] = 1
+    d.a.p0 = d.b = d.out = 0x1000
+    d.a.csplit = 1 << 30
+    with pytest.raises(lib.SdmError, match="multiples of 8"):
+        lib.call("sdm_igemm_bf16", C.byref(d), 0, None)
+    with pytest.raises(lib.SdmError, match="affine_residual_bf16"):
+        lib.call("sdm_affine_residual_bf16", None, 0, None, None, 0, None, 0, None, 0, 0, None, 0, 1, 1, 8, None)
+    with pytest.raises(lib.SdmError, match="transpose_bf16"):
+        lib.call("sdm_transpose_bf16", None, 0, 0, 0, 1, None, 0, 0, 1, 1, 1, None)
 
 
 def test_unet_surface_matches_reference():

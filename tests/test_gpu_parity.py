@@ -483,6 +483,33 @@ def test_baseline_shapes_vs_oracle(dev, O, name, over, n, res):
     assert rel(y, ref) < 2e-5, (name, rel(y, ref))
 
 
+def test_rectangular_images_and_input_checks(dev, O):
+    """Non-square images, odd batch, and the input checks of U_Net.forward (reference: RuntimeError from the channel
+    mismatch of nn.Conv2d / the skip torch.cat when H, W do not divide by 2**num_layers)."""
+    from models.U_Net import U_Net
+    cfg = O.full_cfg(NARROW)
+    net = U_Net(**cfg)
+    P = O.seeded_params(cfg, seed=3, gain=1.8)
+    net.load_state_dict(P, strict=True)
+    net = net.cuda().eval()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 3, 24, 40, generator=g)
+    t = torch.tensor([1, 500, 999])
+    cond = torch.eye(3)[[2, 0, 1]]
+    with torch.no_grad():
+        ref = O.unet_forward(P, cfg, x, t, cond)
+        y = net(x.cuda(), t.cuda(), cond.cuda())
+    assert y.shape == (3, 3, 24, 40)
+    assert rel(y, ref) < 2e-5, rel(y, ref)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="multiples"):
+            net(torch.randn(1, 3, 18, 16, device="cuda"), t[:1].cuda(), cond[:1].cuda())
+        with pytest.raises(RuntimeError, match="expected input"):
+            net(torch.randn(1, 4, 16, 16, device="cuda"), t[:1].cuda(), cond[:1].cuda())
+        with pytest.raises(RuntimeError, match="MI355X only"):
+            net(torch.randn(1, 3, 16, 16), t[:1], cond[:1])
+
+
 # ------------------------------------------------------------------------------------------------
 # super-resolution path (SURVEY §8f rank 1): area interpolation, cold sampler, SR training step
 # ------------------------------------------------------------------------------------------------
