@@ -622,8 +622,32 @@ static int launch_igemm_glds(const IgemmLaunch& L, int ntm, hipStream_t st) {
 }
 
 // Finishes a split-K contraction: ws holds raw sums indexed [out row][N].
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const sdm_igemm_desc d, long long rows) {
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const sdm_igemm_desc d, long long rows, int vec) {
   const long long total = rows * d.N;
+  if (vec) {   // N % 4 == 0 and every row pointer 16-byte aligned: four columns per lane
+    const int N4 = d.N >> 2;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < rows * N4; e += (long long)gridDim.x * 256) {
+      const long long orow = e / N4;
+      const int col = (int)(e - orow * N4) * 4;
+      f32x4* w = (f32x4*)(d.ws + orow * d.N + col);
+      f32x4 v = *w * d.alpha;
+      *w = zero4;
+      if (d.bias) v += *(const f32x4*)(d.bias + col);
+      if (d.out_preact) *(f32x4*)(d.out_preact + orow * d.ldo + col) = v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = sdm_act(v[i], d.act);
+      if (d.res) v += *(const f32x4*)(d.res + orow * d.ldres + col);
+      if (d.res2) v += *(const f32x4*)(d.res2 + orow * d.ldres2 + col);
+      if (d.dact_z && (d.dact_ncols == 0 || col < d.dact_ncols)) {   // dact_ncols is a multiple of 4 on this path
+        const f32x4 zv = *(const f32x4*)(d.dact_z + orow * d.ldz + col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= sdm_dsilu(zv[i]);
+      }
+      *(f32x4*)(d.out + orow * d.ldo + col) = v;
+    }
+    return;
+  }
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const long long orow = e / d.N;
     const int col = (int)(e - orow * d.N);
@@ -822,7 +846,17 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
     int grid = (int)((total + 1023) / 1024);
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, st, *d, (long long)out_rows);
+    const int evec = d->N % 4 == 0 && aligned16(d->ws) && aligned16(d->out) && d->ldo % 4 == 0 &&
+                     (d->bias == nullptr || aligned16(d->bias)) && (d->out_preact == nullptr || aligned16(d->out_preact)) &&
+                     (d->res == nullptr || (aligned16(d->res) && d->ldres % 4 == 0)) &&
+                     (d->res2 == nullptr || (aligned16(d->res2) && d->ldres2 % 4 == 0)) &&
+                     (d->dact_z == nullptr || (aligned16(d->dact_z) && d->ldz % 4 == 0 && d->dact_ncols % 4 == 0));
+    if (evec) {
+      grid = (int)((total / 4 + 255) / 256);
+      if (grid > 4096) grid = 4096;
+      if (grid < 1) grid = 1;
+    }
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, st, *d, (long long)out_rows, evec);
     SDM_CHECK_LAUNCH("splitk_epilogue");
   }
   return SDM_OK;
