@@ -133,7 +133,8 @@ typedef struct sdm_igemm_desc {
   int64_t ldz;
   int dact_ncols;         /* silu'(z) is applied to output columns [0, dact_ncols); 0 = all N */
 
-  float* ws;              /* split-K scratch: M_out_rows*N floats, used only when the library splits K.
+  float* ws;              /* split-K scratch: batch*M_out_rows*N floats (sdm_igemm_workspace_bytes), used only when the
+                             library splits K.
                              CONTRACT: the caller hands it over zero-filled once; every call leaves the part it
                              touched zero-filled again (the finishing pass clears what it reads) */
   size_t ws_bytes;

@@ -20,6 +20,7 @@ struct IgemmLaunch {
   sdm_igemm_desc d;
   int splitk, ntn, kchunks;
   int mfast;   // tile order inside one XCD's run: 0 = N-tiles fastest (A rows shared in L2), 1 = M-tiles fastest (B shared)
+  long long out_rows;   // output rows of ONE batch entry (split-K scratch is [batch][out_rows][N])
 };
 
 // Workgroups go to the 8 XCDs round-robin by linear id and every XCD has its own L2.  Remap blockIdx.x so that one
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
         if (orow < 0) continue;
         float v = acc[i][j][r];
         if (L.splitk > 1) {
-          atomicAdd(&d.ws[orow * N + col], v);
+          atomicAdd(&d.ws[((long long)blockIdx.z * L.out_rows + orow) * N + col], v);
           continue;
         }
         v = v * d.alpha + bias;
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
         if (orow < 0) continue;
         float v = acc[i][j][r];
         if (L.splitk > 1) {
-          atomicAdd(&d.ws[orow * N + col], v);
+          atomicAdd(&d.ws[((long long)blockIdx.z * L.out_rows + orow) * N + col], v);
           continue;
         }
         v = v * d.alpha + bias;
@@ -621,44 +622,51 @@ static int launch_igemm_glds(const IgemmLaunch& L, int ntm, hipStream_t st) {
   return SDM_OK;
 }
 
-// Finishes a split-K contraction: ws holds raw sums indexed [out row][N].
+// Finishes a split-K contraction: ws holds raw sums indexed [batch entry][out row][N]; `rows` = out rows per entry.
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const sdm_igemm_desc d, long long rows, int vec) {
-  const long long total = rows * d.N;
+  const long long all_rows = rows * d.batch;
   if (vec) {   // N % 4 == 0 and every row pointer 16-byte aligned: four columns per lane
     const int N4 = d.N >> 2;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < rows * N4; e += (long long)gridDim.x * 256) {
-      const long long orow = e / N4;
-      const int col = (int)(e - orow * N4) * 4;
-      f32x4* w = (f32x4*)(d.ws + orow * d.N + col);
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < all_rows * N4; e += (long long)gridDim.x * 256) {
+      const long long grow = e / N4;
+      const int col = (int)(e - grow * N4) * 4;
+      const long long b = grow / rows, orow = grow - b * rows;
+      const long long b0 = b / d.bdiv, b1 = b - b0 * d.bdiv;
+      const long long oo = b0 * d.o_bs0 + b1 * d.o_bs1 + orow * d.ldo + col;
+      f32x4* w = (f32x4*)(d.ws + grow * d.N + col);
       f32x4 v = *w * d.alpha;
-      *w = zero4;
+      *w = zero4;      // leave the scratch zero-filled for the next split-K launch
       if (d.bias) v += *(const f32x4*)(d.bias + col);
-      if (d.out_preact) *(f32x4*)(d.out_preact + orow * d.ldo + col) = v;
+      if (d.out_preact) *(f32x4*)(d.out_preact + oo) = v;
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = sdm_act(v[i], d.act);
-      if (d.res) v += *(const f32x4*)(d.res + orow * d.ldres + col);
+      if (d.res) v += *(const f32x4*)(d.res + b0 * d.r_bs0 + b1 * d.r_bs1 + orow * d.ldres + col);
       if (d.res2) v += *(const f32x4*)(d.res2 + orow * d.ldres2 + col);
       if (d.dact_z && (d.dact_ncols == 0 || col < d.dact_ncols)) {   // dact_ncols is a multiple of 4 on this path
         const f32x4 zv = *(const f32x4*)(d.dact_z + orow * d.ldz + col);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] *= sdm_dsilu(zv[i]);
       }
-      *(f32x4*)(d.out + orow * d.ldo + col) = v;
+      *(f32x4*)(d.out + oo) = v;
     }
     return;
   }
+  const long long total = all_rows * d.N;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const long long orow = e / d.N;
-    const int col = (int)(e - orow * d.N);
+    const long long grow = e / d.N;
+    const int col = (int)(e - grow * d.N);
+    const long long b = grow / rows, orow = grow - b * rows;
+    const long long b0 = b / d.bdiv, b1 = b - b0 * d.bdiv;
+    const long long oo = b0 * d.o_bs0 + b1 * d.o_bs1 + orow * d.ldo + col;
     float v = d.ws[e] * d.alpha + (d.bias ? d.bias[col] : 0.f);
     d.ws[e] = 0.f;  // leave the scratch zero-filled for the next split-K launch
-    if (d.out_preact) d.out_preact[orow * d.ldo + col] = v;
+    if (d.out_preact) d.out_preact[oo] = v;
     v = sdm_act(v, d.act);
-    if (d.res) v += d.res[orow * d.ldres + col];
+    if (d.res) v += d.res[b0 * d.r_bs0 + b1 * d.r_bs1 + orow * d.ldres + col];
     if (d.res2) v += d.res2[orow * d.ldres2 + col];
     if (d.dact_z && (d.dact_ncols == 0 || col < d.dact_ncols)) v *= sdm_dsilu(d.dact_z[orow * d.ldz + col]);
-    d.out[orow * d.ldo + col] = v;
+    d.out[oo] = v;
   }
 }
 
@@ -739,12 +747,12 @@ static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* w
     if (c == 0 && N <= 64) continue;
     const long tiles = (long)cdiv(M, kCfgs[c].bm) * cdiv(N, kCfgs[c].bn) * ph;
     for (int sk = 1; sk <= 64; sk *= 2) {
-      if (sk > 1 && (d->batch != 1 || sk > T / 8)) break;
+      if (sk > 1 && sk > T / 8) break;
       const long nb = tiles * sk;
       const long per_cu = (nb + 255) / 256;
       const double overlap = (per_cu >= 2 && kOcc[c] >= 2) ? 0.92 : 1.0;
       double t = (double)per_cu * ((double)T / sk) * (kMfma[c] + kOvh[c] + ((c == 0 || c == 3) ? pen : 0.0)) * overlap + 3000.0;
-      if (sk > 1) t += 6000.0 + (double)out_rows * N * 4.0 * sk / 256.0 / 4.0;   // atomics + finishing launch
+      if (sk > 1) t += 6000.0 + (double)out_rows * d->batch * N * 4.0 * sk / 256.0 / 4.0;   // atomics + finishing launch
       if (t < best) { best = t; bc = c; bs = sk; }
     }
   }
@@ -754,12 +762,12 @@ static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* w
     int fc = -1, fs = 1;
     if (sscanf(force, "%d,%d", &fc, &fs) >= 1 && fc >= 0 && fc < 4) {
       bc = fc;
-      bs = (d->batch == 1 && fs >= 1 && fs <= T) ? fs : 1;
+      bs = (fs >= 1 && fs <= T) ? fs : 1;
     }
   }
   *cfg = bc;
   *splitk = bs;
-  *ws_need = bs > 1 ? (size_t)out_rows * N * sizeof(float) : 0;
+  *ws_need = bs > 1 ? (size_t)out_rows * d->batch * N * sizeof(float) : 0;
 }
 
 extern "C" size_t sdm_igemm_workspace_bytes(const sdm_igemm_desc* d) {
@@ -818,6 +826,7 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
   const bool vecB = aligned16(d->b) && d->ldb % 4 == 0 && d->b_tap_stride % 4 == 0 && d->b_bs0 % 4 == 0 && d->b_bs1 % 4 == 0;
   const bool vec = vecA && vecB && d->K % 4 == 0 && (!d->b_kmajor || d->N % 4 == 0);
   const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
+  L.out_rows = out_rows;
   const int ntm = cdiv(d->M, kCfgs[cfg].bm);
   L.ntn = cdiv(d->N, kCfgs[cfg].bn);
   {
@@ -842,11 +851,12 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
   else rc = dispatch_igemm<128, 64, 2, 2>(L, ntm, km, vec, aff, st);
   if (rc != SDM_OK) return rc;
   if (L.splitk > 1) {
-    const long long total = (long long)out_rows * d->N;
+    const long long total = (long long)out_rows * d->batch * d->N;
     int grid = (int)((total + 1023) / 1024);
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
-    const int evec = d->N % 4 == 0 && aligned16(d->ws) && aligned16(d->out) && d->ldo % 4 == 0 &&
+    const int evec = d->N % 4 == 0 && aligned16(d->ws) && aligned16(d->out) && d->ldo % 4 == 0 && d->o_bs0 % 4 == 0 &&
+                     d->o_bs1 % 4 == 0 && d->r_bs0 % 4 == 0 && d->r_bs1 % 4 == 0 &&
                      (d->bias == nullptr || aligned16(d->bias)) && (d->out_preact == nullptr || aligned16(d->out_preact)) &&
                      (d->res == nullptr || (aligned16(d->res) && d->ldres % 4 == 0)) &&
                      (d->res2 == nullptr || (aligned16(d->res2) && d->ldres2 % 4 == 0)) &&
