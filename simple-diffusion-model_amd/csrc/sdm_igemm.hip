@@ -783,14 +783,14 @@ static int dispatch_igemm(const IgemmLaunch& L, int ntm, bool kmajor, bool vec, 
   static const char* noglds = getenv("SDM_IGEMM_GLDS");
   if (vec && !aff && !(noglds && noglds[0] == '0')) {
     constexpr int NBUF = (BM * BN >= 128 * 128) ? 2 : 3;
+    // Small tiles, at most two workgroups per CU in the grid: 64-deep K-steps with a 2-slot ring (one barrier per 32
+    // MFMAs instead of 16; the same 64 KB of LDS would not allow a third workgroup anyway).  Denser grids keep the
+    // 32-deep / 3-slot form, whose 48 KB lets three workgroups share a CU.  SDM_IGEMM_BK64=0 turns it off.
     static const char* bk64 = getenv("SDM_IGEMM_BK64");
-    if (BM * BN <= 64 * 128 && bk64 && bk64[0] != '0') {       // experimental: 64-deep K-steps for the small tiles
+    const long nblocks = (long)ntm * L.ntn * L.d.nphase * L.splitk * L.d.batch;
+    if (BM * BN <= 64 * 128 && L.d.K % 64 == 0 && nblocks <= 512 && !(bk64 && bk64[0] == '0')) {
       IgemmLaunch L2 = L;
       L2.kchunks = cdiv(L.d.K, 64);
-      const int nb = bk64[0] == '3' ? 3 : 2;
-      if (nb == 3)
-        return kmajor ? launch_igemm_glds<BM, BN, WM, WN, true, 3, 64>(L2, ntm, st)
-                      : launch_igemm_glds<BM, BN, WM, WN, false, 3, 64>(L2, ntm, st);
       return kmajor ? launch_igemm_glds<BM, BN, WM, WN, true, 2, 64>(L2, ntm, st)
                     : launch_igemm_glds<BM, BN, WM, WN, false, 2, 64>(L2, ntm, st);
     }
