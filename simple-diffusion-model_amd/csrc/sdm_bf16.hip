@@ -401,7 +401,7 @@ static int bf_validate(const sdm_igemm_desc* d, int out_f32) {
   return SDM_OK;
 }
 
-// Tile configurations.  Measured on MI355X (profiles/r01_bf16_probe.txt): the contraction saturates near 770 TFLOP/s
+// Tile configurations.  Measured on MI355X (profiles/r01_bf16_probe.txt): the contraction saturates at 800-900 TFLOP/s
 // -- operand movement L2 -> LDS (64 flop per tile byte at 128x128) and LDS fragment reads (one ds_read_b128 per
 // MFMA) run close to their limits together -- and what matters most below that is co-residency: two workgroups per CU
 // hide each other's DMA latency (ring 2, 64 KB: 1.3-1.5x over ring 3 with one workgroup).  A 256x128 / 8-wave tile

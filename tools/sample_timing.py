@@ -8,8 +8,10 @@ torch.manual_seed(0)
 net = U_Net(num_resnet_blocks=1, num_layers=4, attn_layers=[2, 3], time_dim=512, min_channel=128, max_channel=512).cuda().eval()
 sched = degraders.CosineNoiseDegradation(1000)
 quiet = lambda *a, **k: None
-for n in (1, 4):
+for n, dt in ((1, torch.float32), (4, torch.float32), (1, torch.bfloat16), (4, torch.bfloat16)):
+    net.set_inference_dtype(dt)
     x = torch.randn(n, 3, 64, 64, device="cuda")
+    print(dt)
     for use_graph in (True, False):
         S.ddpm_sampling(net, sched, x, 1, 5, device="cuda", log=quiet, use_graph=use_graph)
         torch.cuda.synchronize(); t0 = time.perf_counter()
