@@ -444,6 +444,27 @@ def test_training_steps_golden(dev, O):
     ref_opt.load_state_dict(sd)
 
 
+def test_training_step_hipgraph_replay_matches_eager(dev, O):
+    """The opt-in captured training step (use_graph=True: forward, backward on two streams, per-bucket Adam on a third,
+    device-resident lr/step) replayed three times lands on the same golden losses and parameters as eager stepping."""
+    import degraders as D
+    from sdm_hip.trainer import DiffusionTrainer
+    g = np.load(os.path.join(GOLDEN, "train_narrow.npz"))
+    cfg, net = narrow_net(O)
+    tr = DiffusionTrainer(net, D.CosineNoiseDegradation(1000), lr=2e-3, use_graph=True)
+    for i in range(3):
+        loss = tr.step(T(g[f"x0_{i}"]).cuda(), T(g[f"lab_{i}"]).cuda(), eps=T(g[f"eps_{i}"]).cuda(), t=T(g[f"t_{i}"]).cuda())
+        assert abs(float(loss) - float(g["losses"][i])) < 5e-5, (i, float(loss), float(g["losses"][i]))
+    assert tr.graph is not None
+    bad = []
+    for k, v in net.state_dict().items():
+        got = v.detach().double().cpu().contiguous().flatten()[T(g[f"pidx/{k}"])]
+        ref = T(g[f"pval/{k}"]).double()
+        if not torch.allclose(got, ref, rtol=1e-3, atol=5e-5):
+            bad.append((k, float((got - ref).abs().max())))
+    assert not bad, bad[:8]
+
+
 # ------------------------------------------------------------------------------------------------
 # the reference's own unit test (tests/test_u_net_model.py:7-23) and the other BASELINE shapes
 # ------------------------------------------------------------------------------------------------
