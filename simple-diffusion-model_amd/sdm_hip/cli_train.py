@@ -6,8 +6,10 @@ import logging
 import os
 import pathlib
 
-import torch
-import torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 from custom_dataset.img_dataset import open_dataset
 from degraders import CosineNoiseDegradation, NoiseDegradation
