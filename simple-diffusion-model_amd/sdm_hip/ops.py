@@ -138,7 +138,8 @@ SIDE = _SideStream()
 
 
 class _Workspace:
-    """Zero-filled split-K scratch, grown on demand.  Outgrown buffers are kept referenced: a captured hipGraph may
+    """Zero-filled scratch (split-K partial sums, GroupNorm-backward channel sums), grown on demand; the kernels leave
+    what they touched zero-filled again.  Outgrown buffers are kept referenced: a captured hipGraph may
     still hold their address."""
 
     def __init__(self):
@@ -150,7 +151,8 @@ class _Workspace:
             return None
         if self.buf is None or self.buf.numel() * 4 < nbytes or self.buf.device != device:
             if torch.cuda.is_current_stream_capturing():
-                raise lib.SdmError("split-K workspace must be sized by a warm-up call before graph capture")
+                raise lib.SdmError("zero-filled scratch (split-K / GroupNorm backward) must be sized by a warm-up call before "
+                                   "graph capture")
             if self.buf is not None:
                 self.retired.append(self.buf)
             self.buf = torch.zeros((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)   # zero-filled contract
