@@ -100,9 +100,16 @@ class U_Net(nn.Module):
         if self.cond_emb is not None:
             groups += [("cond_emb", self.cond_emb)]
         live = {id(p) for _, p in self.live_parameters()}
+        # The y_scale projections of every AdaGN are USED until the very end of the backward: their data gradient (the
+        # embedding gradient) is one batched launch after the last block (ops.LinearBank.backward_dx).  An optimizer
+        # that updates a block's parameters as soon as the block has finished must therefore not see them in that
+        # block: they complete -- and are listed -- with the embedding MLP.
+        late = {id(p) for a in self._adagns for p in (a.y_scale.weight, a.y_scale.bias)} if self.cond_emb is not None else set()
         out = []
         for name, mod in groups:
-            ps = [p for p in mod.parameters() if id(p) in live]
+            ps = [p for p in mod.parameters() if id(p) in live and id(p) not in late]
+            if name == "cond_emb":
+                ps += [p for a in self._adagns for p in (a.y_scale.weight, a.y_scale.bias)]
             if ps:
                 out.append((name, ps))
         return out

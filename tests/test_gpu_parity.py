@@ -373,6 +373,61 @@ def test_standard_architecture_vs_oracle(dev, O):
     assert rel(y, ref) < 2e-5, rel(y, ref)
 
 
+def test_standard_architecture_training_step_vs_oracle(dev, O):
+    """The bench workload itself (BASELINE configs[1]: 127 M-parameter U-Net, 64x64, cosine schedule) -- loss and every
+    live gradient tensor of one noise-prediction step against the pinned CPU oracle, then one fused optimiser step
+    against torch.optim.Adam on the oracle's gradients."""
+    import degraders as D
+    from models.U_Net import U_Net
+    from sdm_hip.trainer import DiffusionTrainer
+    cfg = dict(O.STANDARD_CFG)
+    torch.manual_seed(0)
+    net = U_Net(**cfg)
+    P = {k: v.detach().clone().contiguous() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    g = torch.Generator().manual_seed(99)
+    x0 = torch.randn(2, 3, 64, 64, generator=g)
+    eps = torch.randn(2, 3, 64, 64, generator=g)
+    t = torch.tensor([812, 37])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref_loss, _, ref_g = O.loss_and_grads(P, cfg, O.CosineSchedule(1000), x0, t, eps)
+    sched = D.CosineNoiseDegradation(1000)
+    x_t = sched(x0.cuda(), t.cuda(), eps.cuda())
+    loss, grads = net.loss_and_grads(x_t, t.cuda(), None, eps.cuda())
+    assert abs(float(loss) - float(ref_loss)) < 2e-5 * max(1.0, abs(float(ref_loss)))
+    dead = set(O.dead_param_names(cfg))
+    bad = []
+    for k, p in net.named_parameters():
+        if k in dead:
+            continue
+        r = rel(grads[p], ref_g[k])
+        lim = 2e-3 if (".conv_block_" in k and k.endswith("conv_layer.0.bias")) else 3e-4
+        if r > lim:
+            bad.append((k, r))
+    assert not bad, bad[:10]
+    # one optimiser step of the fused trainer == torch.optim.Adam(lr, betas=(0.5, 0.999)) fed the same gradients.  The
+    # trainer updates each gradient bucket while the backward is still running; this also checks that no gradient is
+    # computed from weights that were already updated (the y_scale projections are read until the end of the backward:
+    # they belong to the last bucket).  First-step updates are ~lr*g/(|g|+eps): a wrong gradient shows as a ~lr error.
+    names = [k for k, _ in net.named_parameters() if k not in dead]
+    leaves = [P[k].clone().requires_grad_(True) for k in names]
+    byname = dict(net.named_parameters())
+    opt = torch.optim.Adam(leaves, lr=1e-3, betas=(0.5, 0.999))
+    for leaf, k in zip(leaves, names):
+        leaf.grad = grads[byname[k]].detach().cpu().contiguous().clone()
+    opt.step()
+    tr = DiffusionTrainer(net, sched, lr=1e-3)
+    tr.step(x0.cuda(), eps=eps.cuda(), t=t.cuda())
+    torch.cuda.synchronize()
+    sd = net.state_dict()
+    off = total = 0
+    for leaf, k in zip(leaves, names):
+        d = (sd[k].detach().cpu() - leaf.detach()).abs()
+        off += int((d > 1e-4).sum())
+        total += d.numel()
+    assert off / total < 1e-5, (off, total)
+
+
 # ------------------------------------------------------------------------------------------------
 # samplers (hipGraph replay and eager) and the training step, against reference trajectories
 # ------------------------------------------------------------------------------------------------
