@@ -428,6 +428,47 @@ def test_standard_architecture_training_step_vs_oracle(dev, O):
     assert off / total < 1e-5, (off, total)
 
 
+def test_standard_architecture_three_steps_follow_the_oracle(dev, O):
+    """Three consecutive optimiser steps of the bench workload at a large learning rate against the CPU oracle trainer
+    (stock torch ops + torch.optim.Adam).  Every step's loss depends on all 122 M weights of the step before, so a
+    stale, doubly-applied or half-reduced update anywhere in the asynchronous step (three streams, per-bucket Adam,
+    bucket clearing) shows up in the next loss."""
+    import degraders as D
+    from models.U_Net import U_Net
+    from sdm_hip.trainer import DiffusionTrainer
+    cfg = dict(O.STANDARD_CFG)
+    torch.manual_seed(0)
+    net = U_Net(**cfg)
+    P = {k: v.detach().clone().contiguous() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    otr = O.OracleTrainer(P, cfg, O.CosineSchedule(1000), lr=1e-3)
+    tr = DiffusionTrainer(net, D.CosineNoiseDegradation(1000), lr=1e-3)
+    g = torch.Generator().manual_seed(5)
+    ref, got = [], []
+    for i in range(3):
+        x0 = torch.randn(2, 3, 64, 64, generator=g)
+        eps = torch.randn(2, 3, 64, 64, generator=g)
+        t = torch.randint(1, 1000, (2,), generator=g)
+        ref.append(otr.step(x0, t, eps))
+        got.append(float(tr.step(x0.cuda(), eps=eps.cuda(), t=t.cuda())))
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert abs(a - b) < 3e-4 * max(abs(b), 1e-3), (i, got, ref)
+    # the check has teeth: the third batch on the INITIAL weights gives a clearly different loss
+    with torch.no_grad():
+        stale = float(torch.nn.functional.mse_loss(
+            O.unet_forward(P, cfg, O.q_sample(O.CosineSchedule(1000), x0, t, eps), t, None), eps))
+    assert abs(stale - ref[2]) > 10 * 3e-4 * abs(ref[2]), (stale, ref)
+    torch.cuda.synchronize()
+    sd = net.state_dict()
+    off = total = 0
+    for k, v in otr.P.items():
+        d = (sd[k].detach().cpu() - v.detach()).abs()
+        off += int((d > 1e-3).sum())          # one full step of lr off
+        total += d.numel()
+    assert off / total < 0.02, (off, total)
+
+
 # ------------------------------------------------------------------------------------------------
 # samplers (hipGraph replay and eager) and the training step, against reference trajectories
 # ------------------------------------------------------------------------------------------------
