@@ -469,6 +469,33 @@ def test_standard_architecture_three_steps_follow_the_oracle(dev, O):
     assert off / total < 0.02, (off, total)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_standard_architecture_sampling_vs_oracle(dev, O, use_graph):
+    """BASELINE configs[1]'s sampling side at full size: the last 4 DDPM steps (recorded noise) and a 4-step DDIM run of
+    the 127 M-parameter U-Net, replayed hipGraph and eager, against the oracle samplers."""
+    import degraders as D
+    import diffusion_sampling_algorithms as S
+    from models.U_Net import U_Net
+    cfg = dict(O.STANDARD_CFG)
+    torch.manual_seed(0)
+    net = U_Net(**cfg)
+    P = {k: v.detach().clone().contiguous() for k, v in net.state_dict().items()}
+    net = net.cuda().eval()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    g = torch.Generator().manual_seed(31)
+    xT = torch.randn(2, 3, 64, 64, generator=g)
+    z = torch.randn(4, 2, 3, 64, 64, generator=g)
+    quiet = lambda *a, **k: None
+    ref, _ = O.ddpm_sample(P, cfg, O.CosineSchedule(1000), xT, z, 1, 4)
+    out = S.ddpm_sampling(net, D.CosineNoiseDegradation(1000), xT.cuda(), 1, 4, device="cuda", log=quiet, noise=z.cuda(),
+                          use_graph=use_graph)
+    assert rel(out, ref) < 5e-5, rel(out, ref)
+    ref, _ = O.ddim_sample(P, cfg, O.CosineSchedule(1000), xT, 1, 1000, 300)
+    out = S.ddim_sampling(net, D.CosineNoiseDegradation(1000), xT.cuda(), 1, 1000, None, None, 300, "cuda", quiet,
+                          use_graph=use_graph)
+    assert rel(out, ref) < 5e-5, rel(out, ref)
+
+
 # ------------------------------------------------------------------------------------------------
 # samplers (hipGraph replay and eager) and the training step, against reference trajectories
 # ------------------------------------------------------------------------------------------------
