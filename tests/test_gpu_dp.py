@@ -85,3 +85,58 @@ def test_two_rank_training_equals_single_rank(tmp_path):
         if not torch.allclose(dp["sd"][k], v, rtol=1e-3, atol=2e-4):
             bad.append((k, float((dp["sd"][k] - v).abs().max())))
     assert not bad, bad[:8]
+
+
+# ---- the same property on the bench workload: 127 M parameters, five buckets of >= 64 MB, y_scale projections in the last one
+def _train_std(world, rank):
+    _setup_paths()
+    import degraders as D
+    from models.U_Net import U_Net
+    from oracle import unet_oracle as O
+    from sdm_hip.trainer import DiffusionTrainer
+    torch.manual_seed(0)
+    net = U_Net(**dict(O.STANDARD_CFG)).cuda()
+    tr = DiffusionTrainer(net, D.CosineNoiseDegradation(1000), lr=1e-3)
+    g = torch.Generator().manual_seed(17)
+    x0 = torch.randn(2, 3, 64, 64, generator=g)
+    eps = torch.randn(2, 3, 64, 64, generator=g)
+    t = torch.tensor([640, 90])
+    per = 2 // world
+    sl = slice(rank * per, (rank + 1) * per)
+    loss = float(tr.step(x0[sl].cuda(), eps=eps[sl].cuda(), t=t[sl].cuda()))
+    torch.cuda.synchronize()
+    return {k: v.detach().cpu().contiguous().clone() for k, v in net.state_dict().items()}, loss, len(tr.reducer.buckets)
+
+
+def _worker_std(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sd, loss, nb = _train_std(world, rank)
+        losses = [torch.zeros(1) for _ in range(world)]
+        dist.all_gather(losses, torch.tensor([loss]))
+        if rank == 0:
+            torch.save({"sd": sd, "losses": [float(v) for v in losses], "buckets": nb}, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_rank_standard_architecture(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dp_std.pt")
+    mp.spawn(_worker_std, args=(2, port, out), nprocs=2, join=True)
+    dp = torch.load(out, weights_only=True)
+    assert dp["buckets"] >= 4
+    ref_sd, ref_loss, _ = _train_std(1, 0)
+    assert abs(sum(dp["losses"]) / 2 - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
+    off = total = 0
+    for k, v in ref_sd.items():
+        d = (dp["sd"][k] - v).abs()
+        off += int((d > 1e-4).sum())       # lr = 1e-3: a tenth of one update
+        total += d.numel()
+    assert off / total < 1e-3, (off, total)
