@@ -130,3 +130,26 @@ def test_ddim_step_list_and_schedule_tables():
     b, a, ab = cos.get_timestep_params(torch.tensor([1, 500, 1000]))
     assert float(ab[0]) == pytest.approx(0.99995875, abs=1e-6) and float(b[2]) == pytest.approx(0.999)
     assert cos.host_params(500)[2] == pytest.approx(0.49384364, abs=1e-6)
+
+
+def test_grad_blocks_cover_live_parameters_once_and_keep_y_scale_last():
+    """The flat gradient buffer / data-parallel buckets follow U_Net.grad_blocks(): every live parameter exactly once,
+    and the AdaGN y_scale projections -- still read by the batched embedding-gradient launch at the end of the backward
+    -- only in the final block, so that a per-bucket optimizer update can never run ahead of a gradient that needs them."""
+    from models.U_Net import U_Net
+    net = U_Net(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=32, cond_dim=3, num_layers=2, attn_layers=[1],
+                num_heads=2, dim_per_head=16, min_channel=32, max_channel=64)
+    blocks = net.grad_blocks()
+    listed = [id(p) for _, ps in blocks for p in ps]
+    live = [id(p) for _, p in net.live_parameters()]
+    assert sorted(listed) == sorted(live) and len(set(listed)) == len(listed)
+    names = {id(p): n for n, p in net.named_parameters()}
+    assert blocks[-1][0] == "cond_emb"
+    for bname, ps in blocks[:-1]:
+        assert not any(".adagn.y_scale." in names[id(p)] for p in ps), bname
+    assert sum(".adagn.y_scale." in names[id(p)] for p in blocks[-1][1]) == 2 * len(net._adagns) > 0
+    # a model without embedding has no late parameters and no cond_emb block
+    plain = U_Net(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=None, cond_dim=None, num_layers=2,
+                  attn_layers=[], num_heads=1, dim_per_head=None, min_channel=32, max_channel=64)
+    pb = plain.grad_blocks()
+    assert sorted(id(p) for _, ps in pb for p in ps) == sorted(id(p) for _, p in plain.live_parameters())
