@@ -373,14 +373,15 @@ def test_standard_architecture_vs_oracle(dev, O):
     assert rel(y, ref) < 2e-5, rel(y, ref)
 
 
-def test_standard_architecture_training_step_vs_oracle(dev, O):
+@pytest.mark.parametrize("cond_dim", [None, 10])
+def test_standard_architecture_training_step_vs_oracle(dev, O, cond_dim):
     """The bench workload itself (BASELINE configs[1]: 127 M-parameter U-Net, 64x64, cosine schedule) -- loss and every
     live gradient tensor of one noise-prediction step against the pinned CPU oracle, then one fused optimiser step
     against torch.optim.Adam on the oracle's gradients."""
     import degraders as D
     from models.U_Net import U_Net
     from sdm_hip.trainer import DiffusionTrainer
-    cfg = dict(O.STANDARD_CFG)
+    cfg = dict(O.STANDARD_CFG, cond_dim=cond_dim)
     torch.manual_seed(0)
     net = U_Net(**cfg)
     P = {k: v.detach().clone().contiguous() for k, v in net.state_dict().items()}
@@ -389,11 +390,13 @@ def test_standard_architecture_training_step_vs_oracle(dev, O):
     x0 = torch.randn(2, 3, 64, 64, generator=g)
     eps = torch.randn(2, 3, 64, 64, generator=g)
     t = torch.tensor([812, 37])
+    lab = None if cond_dim is None else torch.eye(cond_dim)[[3, 7]]
+    lab_d = None if lab is None else lab.cuda()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    ref_loss, _, ref_g = O.loss_and_grads(P, cfg, O.CosineSchedule(1000), x0, t, eps)
+    ref_loss, _, ref_g = O.loss_and_grads(P, cfg, O.CosineSchedule(1000), x0, t, eps, lab)
     sched = D.CosineNoiseDegradation(1000)
     x_t = sched(x0.cuda(), t.cuda(), eps.cuda())
-    loss, grads = net.loss_and_grads(x_t, t.cuda(), None, eps.cuda())
+    loss, grads = net.loss_and_grads(x_t, t.cuda(), lab_d, eps.cuda())
     assert abs(float(loss) - float(ref_loss)) < 2e-5 * max(1.0, abs(float(ref_loss)))
     dead = set(O.dead_param_names(cfg))
     bad = []
@@ -417,7 +420,7 @@ def test_standard_architecture_training_step_vs_oracle(dev, O):
         leaf.grad = grads[byname[k]].detach().cpu().contiguous().clone()
     opt.step()
     tr = DiffusionTrainer(net, sched, lr=1e-3)
-    tr.step(x0.cuda(), eps=eps.cuda(), t=t.cuda())
+    tr.step(x0.cuda(), lab_d, eps=eps.cuda(), t=t.cuda())
     torch.cuda.synchronize()
     sd = net.state_dict()
     off = total = 0
