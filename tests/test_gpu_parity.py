@@ -716,6 +716,43 @@ def test_sr_training_steps_golden(dev, O):
     assert not bad, bad[:8]
 
 
+def test_standard_architecture_sr_step_vs_oracle(dev, O):
+    """BASELINE configs[4]'s model (6 input channels, Tanh head) at full width on a 16 -> 64 super-resolution batch: the SR
+    objective of train_SR_diffusion.py:318-374 -- network input, loss and every gradient -- against the oracle."""
+    import degraders as D
+    from models.U_Net import U_Net
+    from sdm_hip.trainer import DiffusionTrainer
+    cfg = dict(O.STANDARD_CFG, in_channel=6, image_recon=True)
+    torch.manual_seed(2)
+    net = U_Net(**cfg)
+    P = {k: v.detach().clone().contiguous() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    g = torch.Generator().manual_seed(77)
+    x0 = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    eps = torch.randn(2, 3, 64, 64, generator=g)
+    t = torch.tensor([450, 999])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sch = O.CosineSchedule(1000)
+    x_in, target = O.sr_batch(sch, x0, t, eps, 16, 64, 250)
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    ref_loss = torch.nn.functional.mse_loss(O.unet_forward(leaves, cfg, x_in, t, None), target)
+    ref_loss.backward()
+    tr = DiffusionTrainer(net, D.CosineNoiseDegradation(1000), lr=0.0, sr=(16, 64, 250))
+    loss = tr.step(x0.cuda(), None, eps=eps.cuda(), t=t.cuda())      # lr = 0: the step leaves weights alone
+    assert abs(float(loss) - float(ref_loss)) < 2e-5 * max(1.0, abs(float(ref_loss))), (float(loss), float(ref_loss))
+    _, grads = net.loss_and_grads(x_in.cuda(), t.cuda(), None, target.cuda())
+    dead = set(O.dead_param_names(cfg))
+    bad = []
+    for k, p in net.named_parameters():
+        if k in dead:
+            continue
+        r = rel(grads[p], leaves[k].grad)
+        lim = 2e-3 if (".conv_block_" in k and k.endswith("conv_layer.0.bias")) else 3e-4
+        if r > lim:
+            bad.append((k, r))
+    assert not bad, bad[:10]
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_classifier_free_guidance_matches_two_pass_oracle(dev, O, use_graph):
     """CFG is a build-side extension (no reference code): the 2N-batch implementation must equal two separate oracle
