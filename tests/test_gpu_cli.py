@@ -50,12 +50,13 @@ def test_train_then_generate(tmp_path):
     (ck / "config.json").write_text(json.dumps({"models": [md]}))
     dest = tmp_path / "gen"
     dest.mkdir()
-    for alg in (["--diff_alg", "ddpm"], ["--diff_alg", "ddim", "--ddim_step_size", "5"]):
+    for alg in (["--diff_alg", "ddpm"], ["--diff_alg", "ddim", "--ddim_step_size", "5"],
+                ["--diff_alg", "ddim", "--ddim_step_size", "5", "--bf16", "--cfg_scale", "2.0"]):
         r = subprocess.run([sys.executable, os.path.join(PKG, "generate_images_diffusion.py"), "-c", str(ck / "config.json"),
                             "--device", "cuda", "-n", "3", "-s", "7", "-d", str(dest), "-l", "0", "1", "0"] + alg,
                            cwd=PKG, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
-    assert len(list((dest / "plots").glob("*.jpg"))) == 2
+    assert len(list((dest / "plots").glob("*.jpg"))) == 3
 
 
 def test_sr_train_then_generate(tmp_path):
@@ -88,8 +89,10 @@ def test_sr_train_then_generate(tmp_path):
     Image.fromarray((np.random.default_rng(0).random((8, 8, 3)) * 255).astype("uint8")).save(lr_path)
     dest = tmp_path / "gen"
     dest.mkdir()
-    r = subprocess.run([sys.executable, os.path.join(PKG, "generate_sr_images_diffusion.py"), "-c", str(ck / "config.json"),
-                        "--device", "cuda", "-s", "7", "-d", str(dest), "--lr_img_path", str(lr_path), "--cold_step_size", "250"],
-                       cwd=PKG, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    assert len(list((dest / "plots").glob("*.jpg"))) == 1
+    for extra in ([], ["--bf16"]):
+        r = subprocess.run([sys.executable, os.path.join(PKG, "generate_sr_images_diffusion.py"), "-c", str(ck / "config.json"),
+                            "--device", "cuda", "-s", "7", "-d", str(dest), "--lr_img_path", str(lr_path),
+                            "--cold_step_size", "250"] + extra,
+                           cwd=PKG, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+    assert len(list((dest / "plots").glob("*.jpg"))) == 2
