@@ -96,3 +96,28 @@ def test_sr_train_then_generate(tmp_path):
                            cwd=PKG, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
     assert len(list((dest / "plots").glob("*.jpg"))) == 2
+
+
+def test_data_parallel_training_command_line(tmp_path):
+    """`torchrun ... train_diffusion.py` with two ranks (gloo rehearsal: both ranks on the one GPU): disjoint shards of
+    every epoch, gradient all-reduce, rank 0 alone writes checkpoints and logs."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = tmp_path / "run"
+    cfg = dict(checkpoint_steps=100, lr_steps=1000, max_epoch=1, plot_img_count=2, use_conditional=False, flip_imgs=True,
+               dataset_path="synthetic:16:3:16:16", out_dir=str(out), model_checkpoint=None, config_checkpoint=None,
+               load_diffusion_optim=False, diffusion_lr=2e-4, batch_size=4, noise_scheduler="COSINE", diffusion_alg="DDPM",
+               min_noise_step=1, max_noise_step=1000, max_actual_noise_step=1000, skip_step=250, in_channel=3, out_channel=3,
+               num_layers=2, num_resnet_block=1, attn_layers=[1], attn_heads=1, attn_dim_per_head=None, time_dim=32,
+               cond_dim=None, min_channel=32, max_channel=64, img_recon=False, seed=5)
+    cfg_path = tmp_path / "train.json"
+    cfg_path.write_text(json.dumps(cfg))
+    env = dict(os.environ, PYTHONPATH=PKG, SDM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29617", os.path.join(PKG, "train_diffusion.py"), "-c", str(cfg_path),
+                        "--device", "cuda"], cwd=PKG, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "x 2 GPU(s)" in r.stderr
+    assert "Steps: 2 / 2" in r.stderr                   # 16 images / (4 per rank x 2 ranks) = 2 steps per epoch
+    ck = out / "checkpoint"
+    assert (ck / "diffusion_2.pt").exists()
