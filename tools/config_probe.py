@@ -69,6 +69,15 @@ def c3():
     t2 = time.perf_counter()
     print(f"C3-shaped DDIM step (128^2, cond 10, CFG on = 2 U-Net passes, batch {n}, fp32): first call {(t1-t0)/ (steps+1)*1e3:.1f} ms/step "
           f"(incl. capture), second {(t2-t1)/(steps+1)*1e3:.1f} ms/step", flush=True)
+    net.set_inference_dtype(torch.bfloat16)
+    S.ddim_sampling(net, sched, noise.clone(), 1, 1000, None, cond, 1000 // steps, DEV, quiet, cfg_scale=2.0)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    S.ddim_sampling(net, sched, noise.clone(), 1, 1000, None, cond, 1000 // steps, DEV, quiet, cfg_scale=2.0)
+    torch.cuda.synchronize()
+    t4 = time.perf_counter()
+    print(f"C3-shaped DDIM step, bf16 storage: {(t4-t3)/(steps+1)*1e3:.1f} ms/step "
+          f"({21.5e12/((t4-t3)/(steps+1))/1e12:.0f} algorithmic TFLOP/s)", flush=True)
 
 
 def train(name, cfg, res, n, sr=None):
