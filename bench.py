@@ -3,14 +3,21 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A *step* is one training pass of the hot path (q-sample -> U-Net forward -> MSE -> backward -> Adam,
-plus the RCCL gradient all-reduce when N > 1) over one synthetic batch: BASELINE.json configs[1]
-("same 64x64 U-Net on 1xMI355X, fp32"), standard architecture of SURVEY.md §8d (127.3 M parameters),
-per-GPU batch 4 (weak scaling: the global batch is 4*N).  `value` = steps all ranks completed / max-over-
-ranks wall time, inputs resident in HBM.  The same JSON line also carries the DDPM sampling rate of the
-hipGraph-captured step (`sample_steps_per_s`), the roofline of the dominant kernel class measured with HIP
-events on the launch stream inside the timed region, and a CPU baseline (the oracle = stock PyTorch-CPU
-ops, the reference's install_cpu_requirements.sh path) on a bounded sample of the same workload.
+Headline (`value`): a *step* is one training pass of the hot path (q-sample -> U-Net forward -> MSE -> backward ->
+Adam, plus the RCCL gradient all-reduce when N > 1) over one synthetic batch of BASELINE.json configs[1] ("same 64x64
+U-Net on 1xMI355X, fp32"): standard architecture of SURVEY.md §8d (127.3 M parameters), per-GPU batch 4 (weak scaling:
+global batch 4*N).  `value` = steps all ranks completed / max-over-ranks wall time, inputs resident in HBM.
+
+The same JSON line also carries
+  * `roofline`: the dominant contraction kernel class of that step, HIP events on the launch stream (by_class: MFMA and
+    HBM fraction of every class);
+  * `configs`: the other BASELINE configurations on this GPU, each with ms/step, steps/s and BOTH roofline fractions
+    (SURVEY §8d "always print both"): c2 DDPM sampling at N=1 / N=4 (fp32 and bf16 storage), c3 DDIM + classifier-free
+    guidance at 128x128 in bf16, c4 per-GPU training step at 128x128 batch 32, c5 SR 64->256 training step at batch 8;
+  * `cpu_baseline`: the oracle (stock PyTorch-CPU ops = the reference's install_cpu_requirements.sh path) on the host
+    cores, BASELINE.md §3: 1 warm-up + 10 timed training steps, N=1 and N=4 forward (sampling-step) rates;
+  * under WORLD_SIZE > 1: `multi_gpu` (RCCL version, ranks, bus GB/s of one 64 MB bucket, all-reduce exposed ms, and
+    the C4 shape -- BASELINE's scaling config -- as c4_steps_per_s).
 """
 import argparse
 import json
@@ -31,43 +38,253 @@ import torch.distributed as dist  # noqa: E402
 
 STANDARD = dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=512, cond_dim=None, num_layers=4,
                 attn_layers=[2, 3], num_heads=1, dim_per_head=None, min_channel=128, max_channel=512, image_recon=False)
-FWD_FLOPS_PER_IMAGE_64 = 41_560_047_616          # SURVEY.md §8d (exact walk)
+# SURVEY.md §8d (exact walk of the module graph): forward FLOPs per image, activation elements per image, live forward
+# parameter elements
+FWD_FLOPS_PER_IMAGE = {64: 41_560_047_616, 128: 168_129_996_800, 256: 703_732_645_888}
+FWD_FLOPS_PER_IMAGE_64 = FWD_FLOPS_PER_IMAGE[64]
+ACT_ELEMS_PER_IMAGE = {64: 16_160_512, 128: 64_578_826, 256: 258_430_720}
+LIVE_PARAMS = 122_192_131
 PEAK_FP32_MFMA_TFLOPS = 157.3                    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (spec)
+PEAK_BF16_MFMA_TFLOPS = 2500.0                   # dense bf16 MFMA (spec; AMD's 5 PF headline includes 2:1 sparsity)
+PEAK_HBM_GBPS = 8000.0                           # HBM3E spec (6.3 TB/s is what a float4 copy reaches)
 
 
-def cpu_baseline(batch, res, steps=3):
-    """Oracle (plain torch CPU ops == the reference's CPU path) training steps on the host cores."""
-    from oracle import unet_oracle as O
+def alg_bytes(n, res, b, train, extra_params=0):
+    """Algorithmic HBM bytes of one step: forward = b*(W + N*A); training = 3*act + 2*weights(b) + fp32
+    weight-gradient write (4 B/param) + Adam 28 B/param."""
+    w, a = LIVE_PARAMS + extra_params, ACT_ELEMS_PER_IMAGE[res] * n
+    return b * (w + a) if not train else 3 * b * a + 2 * b * w + 4 * w + 28 * w
+
+
+def fractions(ms, flops, nbytes, peak_tflops):
+    t = ms * 1e-3
+    return dict(ms_per_step=ms, steps_per_s=1e3 / ms, tflops_algorithmic=flops / t / 1e12,
+                flop_frac=flops / t / 1e12 / peak_tflops, flop_peak_tflops=peak_tflops,
+                hbm_GBps_algorithmic=nbytes / t / 1e9, byte_frac=nbytes / t / 1e9 / PEAK_HBM_GBPS)
+
+
+def host_cores():
+    """Threads for the CPU baseline: the cores this job may actually use = min(affinity mask, cgroup CPU quota)."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))       # a 1-GPU box gives this job a 16-CPU share; more threads only oversubscribe
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                quota = max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    return avail, quota, model
+
+
+def cpu_baseline(batch, res):
+    """oracle (plain torch CPU ops == the reference's CPU path) on the host cores: 1 warm-up + 10 timed
+    training steps of C1, then 1 warm-up + up to 20 timed forwards at N=1 and N=4 (the sampling step), each bounded by a
+    wall-clock budget so that the default bench run stays within minutes."""
+    from oracle import unet_oracle as O
+    avail, quota, model = host_cores()
+    cap = int(os.environ.get("SDM_BENCH_CPU_THREADS", "0"))
+    # a 1-GPU box hands this job a 16-CPU share of a 256-thread host (gpurun: "16 for one GPU"); when no cgroup quota says
+    # otherwise, more threads than that only oversubscribe the share
+    cores = cap if cap > 0 else max(1, min(avail, quota if quota else 16))
     torch.set_num_threads(cores)
-    print(f"[bench] cpu_baseline: os.cpu_count={os.cpu_count()} affinity={avail} threads={cores}", file=sys.stderr, flush=True)
+    print(f"[bench] cpu_baseline: {model}; os.cpu_count={os.cpu_count()} affinity={avail} cgroup_quota={quota} "
+          f"threads={cores}", file=sys.stderr, flush=True)
     torch.manual_seed(0)
     from models.U_Net import U_Net
     net = U_Net(**STANDARD)
     P = {k: v.detach().clone().contiguous() for k, v in net.state_dict().items()}
     del net
-    tr = O.OracleTrainer(P, O.full_cfg(STANDARD), O.CosineSchedule(1000), lr=2e-5)
+    cfg = O.full_cfg(STANDARD)
+    tr = O.OracleTrainer(P, cfg, O.CosineSchedule(1000), lr=2e-5)
     g = torch.Generator().manual_seed(1234)
     x0 = torch.randn(batch, 3, res, res, generator=g)
     eps = torch.randn(batch, 3, res, res, generator=g)
     t = torch.randint(1, 1000, (batch,), generator=g)
-    tw = time.perf_counter()
-    tr.step(x0, t, eps)                                        # warm-up
-    tw = time.perf_counter() - tw
-    print(f"[bench] cpu_baseline: warm-up step {tw:.2f}s", file=sys.stderr, flush=True)
-    steps = max(1, min(steps, int(20.0 / max(tw, 1e-3))))      # bound the sample to ~20 s of CPU work
+
+    def timed(fn, max_n, budget_s):
+        tw = time.perf_counter()
+        fn()                                                       # warm-up
+        tw = time.perf_counter() - tw
+        n = max(1, min(max_n, int(budget_s / max(tw, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        return n, (time.perf_counter() - t0) / n
+
+    n_tr, s_tr = timed(lambda: tr.step(x0, t, eps), 10, 14.0)
+    print(f"[bench] cpu_baseline: train step {s_tr:.3f}s x{n_tr}", file=sys.stderr, flush=True)
+    fw = {}
+    with torch.no_grad():
+        for n in (1, 4):
+            xs, ts = x0[:n], t[:n]
+            k, s = timed(lambda: O.unet_forward(P, cfg, xs, ts, None), 20, 5.0)
+            fw[n] = (k, s)
+    return dict(value=1.0 / s_tr, unit="U-Net train steps/s (batch %d, %dx%d, fwd+bwd+Adam)" % (batch, res, res),
+                cores=cores, kind="port", cpu_model=model, torch=torch.__version__,
+                threads_policy="min(affinity=%d, cgroup quota=%s, 16-CPU share of a 1-GPU box)" % (avail, quota),
+                sample="%d timed C1 training steps after 1 warm-up of the oracle (stock torch CPU ops), same architecture / "
+                       "batch; forward: %d (N=1) and %d (N=4) timed calls after 1 warm-up" % (n_tr, fw[1][0], fw[4][0]),
+                sample_steps_per_s_n1=1.0 / fw[1][1], sample_steps_per_s_n4=1.0 / fw[4][1])
+
+
+def time_gpu(fn, warm, reps):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        tr.step(x0, t, eps)
-    dt = time.perf_counter() - t0
-    return dict(value=steps / dt, unit="U-Net train steps/s (batch %d, %dx%d, fwd+bwd+Adam)" % (batch, res, res),
-                cores=cores, kind="port",
-                sample="%d timed steps after 1 warm-up of the oracle (stock torch %s CPU ops), same architecture/batch"
-                       % (steps, torch.__version__))
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / reps
+
+
+def other_configs(dev, sched, net64):
+    """The other BASELINE configurations on this one GPU (inputs resident in HBM, synthetic Gaussian images, random-init
+    weights).  Each entry: ms/step, steps/s, algorithmic TFLOP/s and GB/s, and both roofline fractions."""
+    import diffusion_sampling_algorithms as S
+    from models.U_Net import U_Net
+    from sdm_hip import lib
+    from sdm_hip.trainer import DiffusionTrainer
+    quiet = lambda *a, **k: None
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(4321)
+
+    # ---- C2 sampling: DDPM hipGraph step at 64x64, N=1 and N=4, fp32 and bf16 storage (T=1000 sampler; K steps timed)
+    def sample_ms(net, n, steps):
+        xT = torch.randn(n, 3, 64, 64, device=dev, generator=g)
+        S.ddpm_sampling(net, sched, xT, 1, 8, device="cuda", log=quiet)                  # warm kernels / scratch sizes
+        torch.cuda.synchronize()
+        l0 = lib.launch_count()
+        t0 = time.perf_counter()
+        S.ddpm_sampling(net, sched, xT, 1, steps, device="cuda", log=quiet)              # includes one graph capture
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        return ms, (lib.launch_count() - l0) // 2      # launches of the eager warm-up pass == launches of the captured step
+
+    for n in (1, 4):
+        for dt, b, peak in ((torch.float32, 4, PEAK_FP32_MFMA_TFLOPS), (torch.bfloat16, 2, PEAK_BF16_MFMA_TFLOPS)):
+            net64.set_inference_dtype(dt)
+            ms, launches = sample_ms(net64, n, 200)
+            rec = fractions(ms, FWD_FLOPS_PER_IMAGE[64] * n, alg_bytes(n, 64, b, False), peak)
+            rec.update(dtype="f32" if b == 4 else "bf16", batch=n, launches_per_step=launches,
+                       what="DDPM step (U-Net forward + update) replayed from a hipGraph, 200 steps incl. one capture")
+            out["c2_sample_n%d_%s" % (n, "fp32" if b == 4 else "bf16")] = rec
+    net64.set_inference_dtype(torch.float32)
+
+    # ---- C3: 128x128, cond_dim=10, bf16, DDIM step with classifier-free guidance (2N batch), N=64
+    torch.manual_seed(0)
+    net = U_Net(**dict(STANDARD, cond_dim=10)).to(dev).eval()
+    n = 64
+    xT = torch.randn(n, 3, 128, 128, device=dev, generator=g)
+    lab = torch.nn.functional.one_hot(torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(1237)), 10).float().to(dev)
+    net.set_inference_dtype(torch.bfloat16)
+    S.ddim_sampling(net, sched, xT, 1, 1000, None, lab, 500, dev, quiet, cfg_scale=3.0)     # warm (3 U-Net calls)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    S.ddim_sampling(net, sched, xT, 1, 1000, None, lab, 100, dev, quiet, cfg_scale=3.0)     # 11 U-Net calls, incl. capture
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / 11
+    rec = fractions(ms, FWD_FLOPS_PER_IMAGE[128] * 2 * n, alg_bytes(2 * n, 128, 2, False, 793_600), PEAK_BF16_MFMA_TFLOPS)
+    rec.update(dtype="bf16", batch=n, unet_batch=2 * n, images_per_s=n * 1e3 / ms,
+               what="DDIM step with classifier-free guidance w=3 (one 2N-image U-Net pass), hipGraph, 11 steps incl. capture")
+    out["c3_ddim_bf16_cfg"] = rec
+    del net, xT
+    torch.cuda.empty_cache()
+
+    # ---- C4 / C5 per-GPU training steps (fp32; and the bf16 training path when the trainer offers it)
+    def train_ms(cfg, res, n, sr, dtype):
+        torch.manual_seed(0)
+        net = U_Net(**cfg).to(dev)
+        kw = {} if dtype == "f32" else {"train_dtype": torch.bfloat16}
+        tr = DiffusionTrainer(net, sched, lr=2e-5, seed=1, sr=sr, **kw)
+        x0 = torch.randn(n, 3, res, res, device=dev, generator=g)
+        tr.step(x0)
+        torch.cuda.synchronize()
+        l0 = lib.launch_count()
+        tr.step(x0)
+        launches = lib.launch_count() - l0
+        ms = time_gpu(lambda: tr.step(x0), 1, 4)
+        del tr, net, x0
+        torch.cuda.empty_cache()
+        return ms, launches
+
+    import inspect
+    has_bf16_train = "train_dtype" in inspect.signature(DiffusionTrainer.__init__).parameters
+    for key, cfg, res, n, sr, extra in (
+            ("c4_train_pergpu", STANDARD, 128, 32, None, 0),
+            ("c5_sr_train_256", dict(STANDARD, in_channel=6, image_recon=True), 256, 8, (64, 256, 100), 3_456)):
+        for dtype in (("f32", "bf16") if has_bf16_train else ("f32",)):
+            ms, launches = train_ms(cfg, res, n, sr, dtype)
+            b, peak = (4, PEAK_FP32_MFMA_TFLOPS) if dtype == "f32" else (2, PEAK_BF16_MFMA_TFLOPS)
+            rec = fractions(ms, 3 * FWD_FLOPS_PER_IMAGE[res] * n, alg_bytes(n, res, b, True, extra), peak)
+            rec.update(dtype=dtype, batch=n, images_per_s=n * 1e3 / ms, launches_per_step=launches,
+                       what="per-GPU training step (q-sample, forward, MSE, backward, Adam), 4 steps timed")
+            out[key + ("" if dtype == "f32" else "_bf16")] = rec
+    return out
+
+
+def multi_gpu_report(dev, world, rank, sched, tr64, x64):
+    """Multi-GPU readiness fields: what RCCL sees, one bucket's bus bandwidth, how much of the all-reduce is exposed, and
+    BASELINE's scaling configuration (C4: 128x128, 32 images per GPU)."""
+    from models.U_Net import U_Net
+    from sdm_hip.trainer import DiffusionTrainer
+    rep = {"backend": dist.get_backend(), "nranks": dist.get_world_size()}
+    try:
+        rep["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        rep["rccl_version"] = None
+    buf = torch.zeros(16 << 20, dtype=torch.float32, device=dev)        # one 64 MB bucket
+    for _ in range(2):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    rep["allreduce_64MB_ms"] = 1e3 * dt
+    rep["allreduce_64MB_busGBps"] = 2.0 * (world - 1) / world * buf.numel() * 4 / dt / 1e9
+    del buf
+    # exposed all-reduce: the same step with the collective switched off (gradients stay local; timing only)
+    def steps_ms(k=8):
+        dist.barrier()
+        return time_gpu(lambda: tr64.step(x64), 1, k)
+    with_ar = steps_ms()
+    tr64.reducer.world = 1
+    without = steps_ms()
+    tr64.reducer.world = world
+    rep["step_ms_with_allreduce"], rep["step_ms_without_allreduce"] = with_ar, without
+    rep["allreduce_exposed_ms"] = with_ar - without
+    # C4 shape under data parallelism
+    torch.manual_seed(0)
+    net = U_Net(**STANDARD).to(dev)
+    tr = DiffusionTrainer(net, sched, lr=2e-5, seed=77)
+    x0 = torch.randn(32, 3, 128, 128, device=dev)
+    dist.barrier()
+    ms = time_gpu(lambda: tr.step(x0), 2, 4)
+    tm = torch.tensor([ms], device=dev, dtype=torch.float64)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    rep["c4_ms_per_step"] = float(tm)
+    rep["c4_steps_per_s"] = 1e3 / float(tm)
+    rep["c4_images_per_s"] = world * 32 * 1e3 / float(tm)
+    rep["c4_config"] = "128x128, 32 images per GPU, fp32, DDPM training, global batch %d" % (32 * world)
+    del tr, net, x0
+    torch.cuda.empty_cache()
+    return rep
 
 
 def main():
@@ -77,7 +294,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch")
     ap.add_argument("--res", type=int, default=64)
-    ap.add_argument("--sample-steps", type=int, default=50, help="DDPM steps timed for the sampling rate (0 = skip)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -97,14 +314,14 @@ def main():
 
     from models.U_Net import U_Net
     import degraders
-    import diffusion_sampling_algorithms as S
     from sdm_hip import lib
+    from sdm_hip import ops as _ops
     from sdm_hip.trainer import DiffusionTrainer
 
     torch.manual_seed(0)
     net = U_Net(**STANDARD).to(dev)
     sched = degraders.CosineNoiseDegradation(1000)
-    tr = DiffusionTrainer(net, sched, lr=2e-5, seed=1235 + rank)
+    tr = DiffusionTrainer(net, sched, lr=2e-5, seed=1235)               # the trainer offsets the seed by the rank
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     x0 = torch.randn(args.batch, 3, args.res, args.res, device=dev, generator=g)
 
@@ -116,17 +333,18 @@ def main():
     for _ in range(args.warmup):
         tr.step(x0)
     barrier()
+    l0 = lib.launch_count()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = tr.step(x0)
     t_enq = time.perf_counter() - t0           # host time to enqueue K steps (GPU still running)
     barrier()
     dt = time.perf_counter() - t0
+    launches_per_step = (lib.launch_count() - l0) / args.steps
     # roofline leg: the same step, eager, with a HIP event pair around every contraction launch on its launch stream
-    # (a replayed hipGraph cannot carry per-kernel events, so this is a second, shorter region of the same workload)
-    # (b) weight-gradient kernels normally overlap data-gradient kernels on a second stream; for the per-kernel
-    # numbers that overlap is switched off so each launch has the chip to itself (same kernels, same shapes)
-    from sdm_hip import ops as _ops
+    # (a replayed hipGraph cannot carry per-kernel events, so this is a second, shorter region of the same workload);
+    # weight-gradient kernels normally overlap data-gradient kernels on a second stream: for the per-kernel numbers that
+    # overlap is switched off so each launch has the chip to itself (same kernels, same shapes)
     graphed = tr.use_graph
     tr.use_graph = False
     side_was = _ops.SIDE.enabled
@@ -150,53 +368,45 @@ def main():
     loss_v = float(loss)
     print(f"[bench] rank {rank}: {args.steps} train steps in {dt:.3f}s", file=sys.stderr, flush=True)
 
-    # ---- sampling rate of the hipGraph-captured DDPM step (rank 0 only, replicas need no collective)
-    sample_rate = sample_rate_bf16 = None
-    if args.sample_steps > 0 and rank == 0:
-        xT = torch.randn(args.batch, 3, args.res, args.res, device=dev, generator=g)
-        quiet = lambda *a, **k: None
-        S.ddpm_sampling(net, sched, xT, 1, 4, device="cuda", log=quiet)                 # warm the graph path
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        S.ddpm_sampling(net, sched, xT, 1, args.sample_steps, device="cuda", log=quiet)
-        torch.cuda.synchronize()
-        sample_rate = args.sample_steps / (time.perf_counter() - ts)     # includes one capture; amortised over T
-        # same sampler with the U-Net in bf16 storage (fp32 accumulation / statistics / sampler state)
-        net.set_inference_dtype(torch.bfloat16)
-        S.ddpm_sampling(net, sched, xT, 1, 4, device="cuda", log=quiet)
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        S.ddpm_sampling(net, sched, xT, 1, args.sample_steps, device="cuda", log=quiet)
-        torch.cuda.synchronize()
-        sample_rate_bf16 = args.sample_steps / (time.perf_counter() - ts)
-        net.set_inference_dtype(torch.float32)
-        print(f"[bench] sampling: {sample_rate:.1f} steps/s fp32, {sample_rate_bf16:.1f} steps/s bf16", file=sys.stderr, flush=True)
-
+    multi = None
     if world > 1:
-        dist.barrier()                      # rank 0 may still have been sampling
+        multi = multi_gpu_report(dev, world, rank, sched, tr, x0)
+        dist.barrier()
     if rank != 0:
         dist.destroy_process_group()
         return
 
+    configs = None
+    if world == 1 and not args.no_configs:
+        del tr
+        configs = other_configs(dev, sched, net.eval())
+        for k, v in configs.items():
+            print(f"[bench] {k}: {v['ms_per_step']:.3f} ms/step, flop_frac {v['flop_frac']:.3f}, byte_frac {v['byte_frac']:.3f}",
+                  file=sys.stderr, flush=True)
+
     # HBM bytes per launch of each class from the committed rocprofv3 PMC passes of this same command
-    # (profiles/r01_hbm_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None when the file is absent
-    traffic = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-            traffic = {k: v["total"] for k, v in json.load(f)["per_class_hbm_bytes_per_launch"].items()}
-    except Exception:
-        pass
+    # (profiles/*_hbm_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None when the file is absent
+    traffic, traffic_file = {}, None
+    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                traffic = {k: v["total"] for k, v in json.load(f)["per_class_hbm_bytes_per_launch"].items()}
+            traffic_file = name
+            break
+        except Exception:
+            pass
     dom = max(prof, key=lambda k: prof[k]["ms"])
     d = prof[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
     step_flops = 3 * FWD_FLOPS_PER_IMAGE_64 * args.batch * (args.res / 64) ** 2
+    step_ms = 1e3 * dt / args.steps
     out = {
         "metric": "U-Net denoise steps/sec (train fwd+bwd+Adam)",
         "value": world * args.steps / dt,
         "unit": "train steps/s (one step = one U-Net fwd+bwd+Adam pass over a batch of %d %dx%d images on one GPU)"
                 % (args.batch, args.res, args.res),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps,
+        "ms_per_step": step_ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: standard 127.3M-param U-Net (L=4,R=1,attn=[2,3],D=512,ch 128..512), "
@@ -205,16 +415,15 @@ def main():
                    "parallelism": "dp%d" % world if world > 1 else "single"},
         "loss": loss_v,
         "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
+        "launches_per_step": launches_per_step,
         "train_step_hipgraph": bool(graphed),
         "step_tflops_algorithmic": step_flops / (dt / args.steps) / 1e12,
-        "sample_steps_per_s": sample_rate,
-        "sample_steps_per_s_bf16": sample_rate_bf16,
-        "sample_config": None if sample_rate is None else "DDPM hipGraph step, batch %d, %d steps timed incl. capture"
-                                                          % (args.batch, args.sample_steps),
+        "step_flop_frac": step_flops / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+        "step_byte_frac": alg_bytes(args.batch, args.res, 4, True) / (dt / args.steps) / 1e9 / PEAK_HBM_GBPS,
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get(dom),
-                     "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
-                                       "bytes per launch)" if dom in traffic else None,
+                     "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; bytes per "
+                                        "launch)" % traffic_file) if dom in traffic else None,
                      "algorithmic_bytes_per_launch": d["bytes"] / max(1, d["launches"]),
                      "hbm_GBps_algorithmic": d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0,
                      "launches": d["launches"], "avg_launch_ms": d["ms"] / max(1, d["launches"]),
@@ -223,9 +432,18 @@ def main():
                                       "has the chip to itself (timed region: side stream %s, hipGraph %s)"
                                       % (prof_steps, 1e3 * dt_prof / prof_steps, "on" if side_was else "off", bool(graphed)),
                      "by_class": {k: {"ms_per_step": v["ms"] / prof_steps, "launches_per_step": v["launches"] / prof_steps,
-                                      "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}
+                                      "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0,
+                                      "mfma_frac": (v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if v["ms"] > 0 else 0.0,
+                                      "hbm_frac": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS) if v["ms"] > 0 else 0.0}
                                   for k, v in prof.items()}},
     }
+    if configs is not None:
+        out["configs"] = configs
+        # kept for continuity with round 1's line (batch-4 DDPM hipGraph step)
+        out["sample_steps_per_s"] = configs["c2_sample_n4_fp32"]["steps_per_s"]
+        out["sample_steps_per_s_bf16"] = configs["c2_sample_n4_bf16"]["steps_per_s"]
+    if multi is not None:
+        out["multi_gpu"] = multi
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.batch, args.res)
     print(json.dumps(out))

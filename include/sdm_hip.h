@@ -53,6 +53,10 @@ size_t sdm_struct_size(int which);
  * under stream capture, where it makes `to` join the capture).  The weight-gradient side stream forks and joins
  * the main stream with it ~70 times per training step. */
 int sdm_stream_order(sdm_stream_t from, sdm_stream_t to);
+/* Number of GPU kernels the library has launched in this process so far (every launch function counts its own kernels,
+ * including finishing passes; memsets and the caller's own torch kernels are not included).  bench.py reports the
+ * difference over one step as launches_per_step. */
+unsigned long long sdm_launch_count(void);
 
 /* Per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg; not capturable, so
  * keep it off inside hipGraph capture).  Classes: 0 igemm 128x128, 1 igemm 64x64, 2 igemm 32x128,
@@ -231,9 +235,12 @@ int sdm_col_softmax_bwd(const float* p, float* dp, int batch, int S, int64_t lds
  * freq[D/2] is the frequency table exp(-i ln(1e4)/(D/2-1)), computed once on the host exactly as the reference does. */
 int sdm_sinusoid(const int64_t* t, const float* freq, int n, int D, float* out, sdm_stream_t s);
 /* Small-batch Linear (+SiLU) for the embedding MLPs and the y_scale projections
- * (custom_layers.py:59-78, :38): out[m][o] = act(sum_k x[m][k] w[o][k] + b[o]) (+ add[m][o]). */
-int sdm_linear_small(const float* x, int64_t ldx, const float* w, const float* b, const float* add,
-                     float* out, int64_t ldo, float* out_preact, int M, int K, int O, int act, sdm_stream_t s);
+ * (custom_layers.py:59-78, :38): out[m][o] = act(sum_k x[m][k] w[o][k] + b[o]) (+ add[m or 0][o]).
+ * add (optional) has add_rows rows of pitch ldadd: either M rows, or ONE row with ldadd == 0 that is broadcast over the
+ * batch (time embedding of a scalar t added to per-image label embeddings, custom_layers.py:97-98); anything else is
+ * rejected. */
+int sdm_linear_small(const float* x, int64_t ldx, const float* w, const float* b, const float* add, int64_t ldadd,
+                     int add_rows, float* out, int64_t ldo, float* out_preact, int M, int K, int O, int act, sdm_stream_t s);
 /* Batched form: njobs projections sharing x (the 16 y_scale GEMVs in one launch). jobs is a DEVICE array. */
 typedef struct sdm_linear_job { const float* w; const float* b; float* out; int O; int pad; } sdm_linear_job;
 int sdm_linear_multi(const float* x, int64_t ldx, int M, int K, const sdm_linear_job* jobs_dev, int njobs,
@@ -291,7 +298,8 @@ int sdm_cold_update(float* x, const float* x0_hat, const float* noise, const flo
 int sdm_area_resize(const float* x, float* out, int planes, int Hin, int Win, int Hout, int Wout, sdm_stream_t s);
 
 /* Step-table cursor for a hipGraph-captured sampling step: t_cur[0] = t_table[*cursor];
- * coef_cur[0..ncoef) = coef_table[*cursor][0..ncoef); ++*cursor (saturating at nsteps-1).  With it the captured
+ * coef_cur[0..ncoef) = coef_table[*cursor][0..ncoef); ++*cursor (saturating at nsteps, reads clamp to the last row, so
+ * *cursor - 1 is the index of the step in flight for all nsteps steps).  With it the captured
  * graph (advance -> U-Net forward -> update) is parameter-free and is simply replayed once per denoise step
  * (the python for-loops of diffusion_sampling_algorithms.py:21-63 and :91-145). */
 int sdm_step_advance(int* cursor, const int64_t* t_table, const float* coef_table, int ncoef, int nsteps,

@@ -11,7 +11,11 @@ int sdm_set_error(int code, const char* fmt, ...) {
   return code;
 }
 
-extern "C" int sdm_version(void) { return 100; }
+unsigned long long g_sdm_launches = 0;
+
+extern "C" int sdm_version(void) { return 200; }
+
+extern "C" unsigned long long sdm_launch_count(void) { return g_sdm_launches; }
 
 extern "C" const char* sdm_last_error(void) { return g_err; }
 

@@ -17,8 +17,11 @@ int sdm_set_error(int code, const char* fmt, ...);
     if (!(cond)) return sdm_set_error(SDM_ERR_ARG, __VA_ARGS__); \
   } while (0)
 
+extern unsigned long long g_sdm_launches;   // kernel launches issued by the library (sdm_launch_count)
+
 #define SDM_CHECK_LAUNCH(name)                                                         \
   do {                                                                                 \
+    ++g_sdm_launches;                                                                  \
     hipError_t e_ = hipGetLastError();                                                 \
     if (e_ != hipSuccess) return sdm_set_error(SDM_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
   } while (0)

@@ -743,8 +743,8 @@ extern "C" int sdm_sinusoid(const int64_t* t, const float* freq, int n, int D, f
 // one wave per output feature; x rows streamed LS_MT at a time
 __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, long long ldx, const float* __restrict__ w,
                                                   const float* __restrict__ b, const float* __restrict__ add,
-                                                  float* __restrict__ out, long long ldo, float* __restrict__ preact,
-                                                  int M, int K, int O, int act, int o, int lane) {
+                                                  long long ldadd, float* __restrict__ out, long long ldo,
+                                                  float* __restrict__ preact, int M, int K, int O, int act, int o, int lane) {
   if (o >= O) return;
   const float* wr = w + (long long)o * K;
   for (int m0 = 0; m0 < M; m0 += LS_MT) {
@@ -764,7 +764,7 @@ __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, l
         float r = v + (b ? b[o] : 0.f);
         if (preact) preact[(long long)(m0 + i) * ldo + o] = r;
         r = sdm_act(r, act);
-        if (add) r += add[(long long)(m0 + i) * ldo + o];
+        if (add) r += add[(long long)(m0 + i) * ldadd + o];   // ldadd 0: one row broadcast over the batch
         out[(long long)(m0 + i) * ldo + o] = r;
       }
     }
@@ -772,17 +772,21 @@ __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, l
 }
 
 __global__ __launch_bounds__(256) void linear_small_kernel(const float* x, long long ldx, const float* w, const float* b,
-                                                           const float* add, float* out, long long ldo, float* preact,
-                                                           int M, int K, int O, int act) {
-  linear_small_body(x, ldx, w, b, add, out, ldo, preact, M, K, O, act, blockIdx.x * 4 + (threadIdx.x >> 6),
+                                                           const float* add, long long ldadd, float* out, long long ldo,
+                                                           float* preact, int M, int K, int O, int act) {
+  linear_small_body(x, ldx, w, b, add, ldadd, out, ldo, preact, M, K, O, act, blockIdx.x * 4 + (threadIdx.x >> 6),
                     threadIdx.x & 63);
 }
 
-extern "C" int sdm_linear_small(const float* x, int64_t ldx, const float* w, const float* b, const float* add, float* out,
-                                int64_t ldo, float* out_preact, int M, int K, int O, int act, sdm_stream_t s) {
+extern "C" int sdm_linear_small(const float* x, int64_t ldx, const float* w, const float* b, const float* add, int64_t ldadd,
+                                int add_rows, float* out, int64_t ldo, float* out_preact, int M, int K, int O, int act,
+                                sdm_stream_t s) {
   SDM_CHECK_ARG(x && w && out && M > 0 && K > 0 && O > 0, "linear_small: bad args");
-  hipLaunchKernelGGL(linear_small_kernel, dim3(cdiv(O, 4)), dim3(256), 0, (hipStream_t)s, x, (long long)ldx, w, b, add, out,
-                     (long long)ldo, out_preact, M, K, O, act);
+  SDM_CHECK_ARG(add == nullptr || (add_rows == M && ldadd >= O) || (add_rows == 1 && ldadd == 0),
+                "linear_small: addend has %d rows (pitch %lld) for a batch of %d: needs M rows, or 1 row with pitch 0", add_rows,
+                (long long)ldadd, M);
+  hipLaunchKernelGGL(linear_small_kernel, dim3(cdiv(O, 4)), dim3(256), 0, (hipStream_t)s, x, (long long)ldx, w, b, add,
+                     (long long)ldadd, out, (long long)ldo, out_preact, M, K, O, act);
   SDM_CHECK_LAUNCH("linear_small");
   return SDM_OK;
 }
@@ -790,7 +794,7 @@ extern "C" int sdm_linear_small(const float* x, int64_t ldx, const float* w, con
 __global__ __launch_bounds__(256) void linear_multi_kernel(const float* x, long long ldx, int M, int K,
                                                            const sdm_linear_job* jobs) {
   const sdm_linear_job j = jobs[blockIdx.y];
-  linear_small_body(x, ldx, j.w, j.b, nullptr, j.out, (long long)j.O, nullptr, M, K, j.O, SDM_ACT_NONE,
+  linear_small_body(x, ldx, j.w, j.b, nullptr, 0, j.out, (long long)j.O, nullptr, M, K, j.O, SDM_ACT_NONE,
                     blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
@@ -1083,11 +1087,12 @@ extern "C" int sdm_area_resize(const float* x, float* out, int planes, int Hin, 
 
 __global__ void step_advance_kernel(int* cursor, const int64_t* t_table, const float* coef_table, int ncoef, int nsteps,
                                     int64_t* t_cur, float* coef_cur) {
-  const int c = *cursor;
+  const int raw = *cursor;
+  const int c = raw < nsteps ? raw : nsteps - 1;      // reads stay inside the tables however often the step is replayed
   if (threadIdx.x == 0) t_cur[0] = t_table[c];
   if (threadIdx.x < ncoef) coef_cur[threadIdx.x] = coef_table[(long long)c * ncoef + threadIdx.x];
   __syncthreads();
-  if (threadIdx.x == 0) *cursor = c + 1 < nsteps ? c + 1 : nsteps - 1;
+  if (threadIdx.x == 0) *cursor = raw < nsteps ? raw + 1 : nsteps;   // cursor - 1 == index of the step being run
 }
 extern "C" int sdm_step_advance(int* cursor, const int64_t* t_table, const float* coef_table, int ncoef, int nsteps,
                                 int64_t* t_cur, float* coef_cur, sdm_stream_t s) {

@@ -1,7 +1,8 @@
 """Image datasets with the reference's conventions (custom_dataset/img_dataset.py, conditional_img_dataset.py):
 float CHW tensors in BGR channel order scaled to [-1, 1].  cv2 / TinyDB are not required: images are decoded
-with PIL, the labelled variant reads the same TinyDB JSON file ({"_default": {"1": {"filepath":..., "labels": {...}}}})
-with the json module.  ``synthetic:N:C:H:W`` yields seeded Gaussian images (benchmarks, smoke tests)."""
+with PIL, the labelled variant reads the reference's TinyDB JSON file with the json module -- table "Data" holds one
+record per image ({"filename": ..., "<label>": value, ...}), table "Labels" one record {"labels": [names]}
+(conditional_img_dataset.py:19-36).  ``synthetic:N:C:H:W`` yields seeded Gaussian images (benchmarks, smoke tests)."""
 import glob
 import json
 import os
@@ -48,23 +49,38 @@ class ImageDataset(Dataset):
 
 
 class ConditionalImgDataset(Dataset):
-    def __init__(self, dataset_path):
+    """TinyDB file of the reference (custom_dataset/conditional_img_dataset.py:14-36): tables "Data" and "Labels"; same
+    exceptions when either is empty; the initial shuffle of the records is kept (seedable through ``random``)."""
+
+    def __init__(self, dataset_path=None):
+        import random
         with open(dataset_path) as f:
-            table = json.load(f).get("_default", {})
-        self.records = [table[k] for k in sorted(table, key=lambda s: int(s))]
-        self.labels = list(self.records[0]["labels"].keys()) if self.records else []
+            db = json.load(f)
+        data_tbl, labels_tbl = db.get("Data", {}), db.get("Labels", {})
+        if len(data_tbl) <= 0:
+            raise Exception("No data found in Data table.")
+        if len(labels_tbl) <= 0:
+            raise Exception("No data found in Labels table.")
+        by_id = lambda tbl: [tbl[k] for k in sorted(tbl, key=lambda s: int(s))]      # TinyDB.all() order: document id
+        self.all_labels = by_id(labels_tbl)[0]["labels"]
+        self.all_data = by_id(data_tbl)
+        random.shuffle(self.all_data)
         self.root = os.path.dirname(os.path.abspath(dataset_path))
+        self.dataset = [(d["filename"], [float(d[label]) for label in self.all_labels]) for d in self.all_data]
 
     def get_labels(self):
-        return self.labels
+        return self.all_labels
 
     def __len__(self):
-        return len(self.records)
+        return len(self.dataset)
 
     def __getitem__(self, i):
-        r = self.records[i]
-        path = r["filepath"] if os.path.isabs(r["filepath"]) else os.path.join(self.root, r["filepath"])
-        return _load_bgr(path), torch.tensor([float(r["labels"][k]) for k in self.labels])
+        if len(self.dataset) <= 0:
+            raise Exception("No data found in dataset.")
+        path, labels = self.dataset[i]
+        if not os.path.isabs(path) and not os.path.exists(path):
+            path = os.path.join(self.root, path)
+        return _load_bgr(path), torch.Tensor(labels)
 
 
 def open_dataset(dataset_path, use_conditional, cond_dim=None):

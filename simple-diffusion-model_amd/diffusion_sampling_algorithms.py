@@ -64,7 +64,7 @@ class _StepRunner:
     def z(self):
         if self.noise is None:
             return torch.randn(self.x.shape, device=self.x.device)
-        idx = (self.cursor - 1).clamp_(min=0).to(torch.int64)        # cursor already advanced for this step
+        idx = (self.cursor - 1).clamp_(min=0).to(torch.int64)        # cursor already advanced for this step (it runs to nsteps)
         return self.noise.index_select(0, idx)[0]
 
     def run(self, body, on_step):

@@ -232,15 +232,27 @@ class ConditionalEmbedding(nn.Module):
         self.register_buffer("_freq", freq, persistent=False)
 
     def run(self, ctx, t, cond=None):
+        """time_layer(sinusoid(t)) + cond_layer(cond) with the reference's broadcasting (custom_layers.py:92-98): t of
+        shape [1] against labels [n, cond_dim] (the samplers at every checkpoint plot) or t [N] against one label row."""
         rec = {} if ctx.train else None
         t = t.reshape(-1).to(torch.int64).contiguous()
-        pe = ops.sinusoid(t, self._freq, self.time_dim)
-        emb = self._mlp(self.time_layer, pe, None, rec, "time")
+        c = None
         if self.cond_layer is not None:
             c = cond.to(torch.float32)
             if c.dim() == 1:
                 c = c[None, :]
-            emb = self._mlp(self.cond_layer, c.contiguous(), emb, rec, "cond")
+            T, n = t.shape[0], c.shape[0]
+            if T != n and T != 1 and n != 1:
+                raise RuntimeError(f"The size of tensor a ({T}) must match the size of tensor b ({n}) at non-singleton "
+                                   "dimension 0")
+            if n == 1 and T > 1:
+                c = c.expand(T, -1)                  # one label row for the whole batch
+            if rec is not None and T == 1 and n > 1:
+                t = t.expand(n).contiguous()         # training keeps one embedding row per image on both branches
+        pe = ops.sinusoid(t, self._freq, self.time_dim)
+        emb = self._mlp(self.time_layer, pe, None, rec, "time")
+        if c is not None:
+            emb = self._mlp(self.cond_layer, c.contiguous(), emb, rec, "cond")     # emb may be ONE row: broadcast add
         if rec is not None:
             ctx.rec[self] = rec
         return emb

@@ -155,12 +155,15 @@ def run_training(sr=False):
                 x0, labels = data.to(dev, non_blocking=True), None
             x0 = x0.float()
             if cfg["flip_imgs"]:                   # per-image horizontal flip with p = 0.5 (:312-314)
-                flip = torch.rand(x0.shape[0], device=dev) < 0.5
+                flip = torch.rand(x0.shape[0], device=dev, generator=trainer.gen) < 0.5     # per-rank stream
                 x0 = torch.where(flip[:, None, None, None], x0.flip(-1), x0)
             loss = trainer.step(x0, labels)
+            if world > 1:                          # global mean loss; a NaN on any rank reaches every rank, so all ranks
+                dist.all_reduce(loss)              # raise together instead of leaving peers blocked in the next all-reduce
+                loss = loss / world
             loss_v = float(loss)                   # the step's only host sync (the reference has two, :354,:366)
-            if loss_v != loss_v:
-                raise Exception("NaN encountered during training")
+            if loss_v != loss_v:                   # (deviation: the fused Adam of this step has already been enqueued; the
+                raise Exception("NaN encountered during training")   # reference raises before optimizer.step, :354-358)
             total += loss_v
 
             if global_steps % cfg["lr_steps"] == 0 and global_steps > 0:

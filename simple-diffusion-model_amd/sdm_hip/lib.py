@@ -83,6 +83,7 @@ _PROTOS = {
     "sdm_device_info": (C.c_int, [C.POINTER(C.c_int)]),
     "sdm_struct_size": (_sz, [_i]),
     "sdm_stream_order": (_i, [fp, fp]),
+    "sdm_launch_count": (C.c_ulonglong, []),
     "sdm_prof_begin": (_i, [_i]),
     "sdm_prof_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sdm_igemm": (_i, [C.POINTER(IgemmDesc), fp]),
@@ -101,7 +102,7 @@ _PROTOS = {
     "sdm_col_softmax": (_i, [fp, _i, _i, _i64, fp]),
     "sdm_col_softmax_bwd": (_i, [fp, fp, _i, _i, _i64, _f, fp]),
     "sdm_sinusoid": (_i, [fp, fp, _i, _i, fp, fp]),
-    "sdm_linear_small": (_i, [fp, _i64, fp, fp, fp, fp, _i64, fp, _i, _i, _i, _i, fp]),
+    "sdm_linear_small": (_i, [fp, _i64, fp, fp, fp, _i64, _i, fp, _i64, fp, _i, _i, _i, _i, fp]),
     "sdm_linear_multi": (_i, [fp, _i64, _i, _i, fp, _i, _i, fp]),
     "sdm_linear_multi_bwd_dx": (_i, [fp, fp, fp, _i, fp, _i64, _i, _i, fp]),
     "sdm_linear_small_bwd": (_i, [fp, _i64, fp, _i64, fp, fp, _i64, _i, fp, fp, _i, _i, _i, fp]),
@@ -157,6 +158,10 @@ def raw(name):
 
 def version():
     return _lib.sdm_version()
+
+
+def launch_count():
+    return int(_lib.sdm_launch_count())
 
 
 PROF_CLASSES = ("igemm_128x128", "igemm_64x64", "igemm_32x128", "wgrad_128x128", "wgrad_64x64", "igemm_128x64")

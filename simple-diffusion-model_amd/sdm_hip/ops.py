@@ -345,8 +345,9 @@ def conv_wgrad(g, g_hw, x, kind, dwt, accumulate=2, dbias=None):
         colsum(g, dbias)
 
 
-def linear_rows(x, W, b, act=ACT_NONE, res=None, save_z=False, out=None):
-    """Token linear on the matrix cores: x [rows, K] (any pitch) @ W[O, K]^T + b (+ res)."""
+def linear_rows(x, W, b, act=ACT_NONE, res=None, save_z=False, out=None, ldres=None):
+    """Token linear on the matrix cores: x [rows, K] (any pitch) @ W[O, K]^T + b (+ res).  ``ldres`` overrides the row
+    pitch of ``res`` (0 = one row broadcast over all rows)."""
     rows, K = x.shape
     O = W.shape[0]
     bf = W.dtype == BF16
@@ -363,7 +364,9 @@ def linear_rows(x, W, b, act=ACT_NONE, res=None, save_z=False, out=None):
     d.out, d.ldo = _p(out), out.stride(0)
     d.bias, d.act = _p(b), act
     if res is not None:
-        d.res, d.ldres = _p(res), res.stride(0)
+        if ldres is None and res.shape[0] != rows:
+            raise lib.SdmError(f"linear_rows: residual has {res.shape[0]} rows for {rows} output rows")
+        d.res, d.ldres = _p(res), res.stride(0) if ldres is None else ldres
     _launch_igemm(d, x.device, bf16=bf)
     return out
 
@@ -643,16 +646,23 @@ def sinusoid(t, freq, D):
 
 
 def linear_small(x, W, b, act=ACT_NONE, add=None, save_z=False):
+    """``add`` (optional) has M rows, or ONE row that is broadcast over the batch (time embedding of a scalar t added to
+    per-image label embeddings, custom_layers.py:97-98)."""
     M, K = x.shape
     O = W.shape[0]
+    ldadd = 0
+    if add is not None:
+        if add.shape[0] not in (1, M) or add.shape[1] != O:
+            raise lib.SdmError(f"linear_small: addend of shape {tuple(add.shape)} does not broadcast to ({M}, {O})")
+        ldadd = add.stride(0) if add.shape[0] == M else 0
     if M >= 32 and not save_z and K % 4 == 0 and x.stride(0) % 4 == 0:
         # one-wave-per-feature GEMV kernel is for the small batches of sampling / batch-4 training; from a few dozen
         # rows on (guided sampling at batch 64-128) the matrix-core path is faster (141 us -> ~10 us at M=128)
-        return linear_rows(x, W, b, act, res=add)
+        return linear_rows(x, W, b, act, res=add, ldres=None if add is None else ldadd)
     out = torch.empty((M, O), dtype=torch.float32, device=x.device)
     z = torch.empty_like(out) if save_z else None
-    lib.call("sdm_linear_small", _p(x), x.stride(0), _p(W), _p(b), _p(add), _p(out), out.stride(0), _p(z), M, K, O, act,
-             _stream())
+    lib.call("sdm_linear_small", _p(x), x.stride(0), _p(W), _p(b), _p(add), ldadd, 0 if add is None else add.shape[0], _p(out),
+             out.stride(0), _p(z), M, K, O, act, _stream())
     return (out, z) if save_z else out
 
 

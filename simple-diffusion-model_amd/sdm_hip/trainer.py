@@ -121,9 +121,14 @@ class DiffusionTrainer:
             use_graph = os.environ.get("SDM_TRAIN_GRAPH", "0") == "1"
         self.use_graph = bool(use_graph) and self.world == 1
         self.graph, self.g_key, self.hyper = None, None, None
+        # per-rank RNG stream for eps / t (and the CLI's flip mask): under data parallelism every rank must draw its own
+        # noise and timesteps for its own images, so the seed is offset by the rank; unseeded runs take a fresh random seed
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         self.gen = torch.Generator(device=dev)
         if seed is not None:
-            self.gen.manual_seed(seed)
+            self.gen.manual_seed(int(seed) * self.world + self.rank)
+        else:
+            self.gen.seed()
         if self.world > 1:                            # identical replicas: rank 0's parameters everywhere
             for p in net.parameters():      # dense storage view: conv weights are permuted (non-contiguous) views
                 dist.broadcast(p.data.as_strided((p.numel(),), (1,), p.storage_offset()), src=0, group=self.pg)
@@ -159,16 +164,20 @@ class DiffusionTrainer:
             self.flat[s:e].zero_()
             self._cleared += e - s
 
+    def sr_inputs(self, x0, eps, t):
+        """(network input, regression target) of the super-resolution objective (train_SR_diffusion.py:318-374): the net sees
+        cat(q(x0, t), q(lowres(x0), cond_t)) -- the SAME eps in both -- and regresses x0 - lowres(x0)."""
+        lr_dim, sr_dim, cond_t = self.sr
+        low = ops.area_resize(ops.area_resize(x0, (lr_dim, lr_dim)), (sr_dim, sr_dim))
+        abar_c = self.schedule.alpha_bar_of(torch.full((x0.shape[0],), int(cond_t), dtype=torch.int64, device=self.dev))
+        x_t = ops.q_sample(x0, eps, self.schedule.alpha_bar_of(t))
+        return torch.cat((x_t, ops.q_sample(low, eps, abar_c)), dim=1), x0 - low
+
     def _body(self, x0, labels, eps, t, hyper=None):
-        abar = self.schedule.alpha_bar_of(t)
-        x_t = ops.q_sample(x0, eps, abar)
-        target = eps
         if self.sr is not None:
-            lr_dim, sr_dim, cond_t = self.sr
-            low = ops.area_resize(ops.area_resize(x0, (lr_dim, lr_dim)), (sr_dim, sr_dim))
-            abar_c = self.schedule.alpha_bar_of(torch.full((x0.shape[0],), int(cond_t), dtype=torch.int64, device=self.dev))
-            x_t = torch.cat((x_t, ops.q_sample(low, eps, abar_c)), dim=1)
-            target = x0 - low
+            x_t, target = self.sr_inputs(x0, eps, t)
+        else:
+            x_t, target = ops.q_sample(x0, eps, self.schedule.alpha_bar_of(t)), eps
         if getattr(self, "_cleared", 0) != self.flat.numel():
             self.flat.zero_()                           # first step, or the previous one did not finish: start clean
         self._cleared = 0                               # backward accumulates (split-K atomics, column sums)

@@ -15,13 +15,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from sdm_hip import lib
     hdr = open(os.path.join(ROOT, "include", "sdm_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|size_t|const char\*)\s+(sdm_\w+)\s*\(", hdr, re.M))
+    declared = set(re.findall(r"^\s*(?:int|size_t|const char\*|unsigned long long)\s+(sdm_\w+)\s*\(", hdr, re.M))
     assert len(declared) >= 30
     missing = [n for n in sorted(declared) if not hasattr(lib._lib, n)]
     assert not missing, missing
     unbound = sorted(declared - set(lib.EXPORTS))
     assert not unbound, f"declared in the header but not bound in sdm_hip/lib.py: {unbound}"
-    assert lib.version() >= 100
+    assert lib.version() >= 200
     # struct layout agreement is asserted at import; re-check one explicitly
     import ctypes as C
     assert lib._lib.sdm_struct_size(0) == C.sizeof(lib.IgemmDesc)
@@ -153,3 +153,47 @@ def test_grad_blocks_cover_live_parameters_once_and_keep_y_scale_last():
                   attn_layers=[], num_heads=1, dim_per_head=None, min_channel=32, max_channel=64)
     pb = plain.grad_blocks()
     assert sorted(id(p) for _, ps in pb for p in ps) == sorted(id(p) for _, p in plain.live_parameters())
+
+
+def test_linear_small_rejects_an_addend_that_does_not_cover_the_batch():
+    """a 1-row time embedding added to n label rows used to be read as n rows.  The addend now travels
+    with its row count and pitch, and anything but M rows / one broadcast row is refused before any launch."""
+    from sdm_hip import lib
+    p = 0x1000
+    with pytest.raises(lib.SdmError, match="addend has 1 rows"):
+        lib.call("sdm_linear_small", p, 32, p, p, p, 32, 1, p, 32, None, 4, 32, 32, 0, None)     # 1 row but pitch != 0
+    with pytest.raises(lib.SdmError, match="addend has 2 rows"):
+        lib.call("sdm_linear_small", p, 32, p, p, p, 32, 2, p, 32, None, 4, 32, 32, 0, None)
+
+
+def test_conditional_dataset_reads_the_reference_tinydb_schema(tmp_path):
+    """custom_dataset/conditional_img_dataset.py:19-36: table "Data" (filename + one key per label) and table "Labels"
+    ({"labels": [...]}); same exceptions when a table is empty."""
+    import numpy as np
+    from PIL import Image
+    from custom_dataset.img_dataset import ConditionalImgDataset, open_dataset
+    rgb = np.zeros((4, 6, 3), dtype=np.uint8)
+    rgb[..., 0], rgb[..., 2] = 255, 0                     # pure red in RGB
+    rgb[..., 1] = 127
+    for name in ("a.png", "b.png"):
+        Image.fromarray(rgb).save(tmp_path / name)
+    db = {"Data": {"1": {"filename": str(tmp_path / "a.png"), "smiling": 1, "glasses": 0.0},
+                   "2": {"filename": "b.png", "smiling": 0, "glasses": 1}},
+          "Labels": {"1": {"labels": ["smiling", "glasses"]}}}
+    path = tmp_path / "db.json"
+    path.write_text(json.dumps(db))
+    ds = open_dataset(str(path), True, 2)
+    assert isinstance(ds, ConditionalImgDataset) and len(ds) == 2 and ds.get_labels() == ["smiling", "glasses"]
+    seen = {}
+    for i in range(2):
+        img, lab = ds[i]
+        assert img.shape == (3, 4, 6) and img.dtype == torch.float32 and lab.dtype == torch.float32
+        assert float(img[0].max()) == -1.0 and float(img[2].min()) == 1.0          # BGR order, scaled to [-1, 1]
+        seen[tuple(lab.tolist())] = True
+    assert seen == {(1.0, 0.0): True, (0.0, 1.0): True}
+    (tmp_path / "empty.json").write_text(json.dumps({"Data": {}, "Labels": db["Labels"]}))
+    with pytest.raises(Exception, match="No data found in Data table"):
+        ConditionalImgDataset(str(tmp_path / "empty.json"))
+    (tmp_path / "nolabels.json").write_text(json.dumps({"Data": db["Data"]}))
+    with pytest.raises(Exception, match="No data found in Labels table"):
+        ConditionalImgDataset(str(tmp_path / "nolabels.json"))
