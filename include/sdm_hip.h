@@ -317,23 +317,26 @@ int sdm_adam_multi(const sdm_adam_job* jobs_dev, int njobs, int64_t max_n, float
  * softmax, biases, modulation tables and the sampler state stay fp32.  The reference has no bf16 mode (its GPU path
  * is fp16 autocast, train_diffusion.py:333): the parity gate of this path is rel-L2 <= 1e-2 against the fp32 oracle. */
 
-/* Same contraction as sdm_igemm with a.p0 / a.p1 / b / res / res2 (and out unless out_f32) pointing at bf16 data; every
- * pitch and stride counts ELEMENTS.  Restrictions: b K-contiguous (b_kmajor = 0), K and csplit multiples of 8, rows
- * 16-byte aligned, no affine-on-load / out_preact / dact_z (training features).  out_f32 != 0 writes fp32 (attention
- * scores ahead of the softmax).  Split-K scratch: fp32, zero-filled, sdm_igemm_bf16_workspace_bytes(d). */
+/* Same contraction as sdm_igemm with a.p0 / a.p1 / b / res / res2 / out_preact / dact_z (and out unless out_f32) pointing at
+ * bf16 data; every pitch and stride counts ELEMENTS.  Restrictions: b K-contiguous (b_kmajor = 0: a data gradient
+ * contracts against a transposed weight copy), K and csplit multiples of 8, rows 16-byte aligned, no affine-on-load.
+ * out_f32 != 0 writes fp32 (attention scores ahead of the softmax; no residual / out_preact then).  Split-K scratch: fp32,
+ * zero-filled, sdm_igemm_bf16_workspace_bytes(d). */
 int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t s);
 size_t sdm_igemm_bf16_workspace_bytes(const sdm_igemm_desc* d);
 /* fp32 -> bf16, round to nearest even (weights, once per checkpoint). */
 int sdm_cast_bf16(const float* src, uint16_t* dst, size_t n, sdm_stream_t s);
-/* sdm_stem_conv / sdm_head_conv with the NHWC side in bf16 (weights, bias and the NCHW image stay fp32). */
-int sdm_stem_conv_bf16(const float* x_nchw, const float* w_tap, const float* bias, uint16_t* out_nhwc,
+/* sdm_stem_conv / sdm_head_conv with the NHWC side in bf16 (weights, bias and the NCHW image stay fp32); out_preact
+ * (optional, bf16) receives the pre-activation for the backward of the bf16 training path. */
+int sdm_stem_conv_bf16(const float* x_nchw, const float* w_tap, const float* bias, uint16_t* out_nhwc, uint16_t* out_preact,
                        int images, int Cin, int H, int W, int Cout, int act, sdm_stream_t s);
 int sdm_head_conv_bf16(const uint16_t* x_nhwc, const float* w_tap, const float* bias, float* out_nchw,
                        int images, int Cin, int H, int W, int Cout, int act, sdm_stream_t s);
-/* sdm_gn_affine on bf16 rows (fp32 tables out; mean / rstd are not returned: no backward on this path). */
+/* sdm_gn_affine on bf16 rows (fp32 tables out); mean / rstd [images][groups] are optional (both or neither): the training
+ * path's backward needs them, sampling passes NULL. */
 int sdm_gn_affine_bf16(const uint16_t* y, int64_t ldy, int images, int HW, int C, int groups, float eps,
                        const float* gamma, const float* beta, const float* mod, int mod_nstride,
-                       float* scale, float* shift, sdm_stream_t s);
+                       float* scale, float* shift, float* mean, float* rstd, sdm_stream_t s);
 /* out = scale*y + shift (+ cat(x0,x1)) on bf16 rows; x0 NULL = affine only (materialises the next conv's input). */
 int sdm_affine_residual_bf16(const uint16_t* y, int64_t ldy, const float* scale, const float* shift, int aff_nstride,
                              const uint16_t* x0, int64_t ldx0, const uint16_t* x1, int64_t ldx1, int csplit,
@@ -345,6 +348,44 @@ int sdm_col_softmax_bf16(const float* scores, uint16_t* P, int batch, int S, int
  * the token index contiguous for P.V (the matrix cores take both operands contiguous along the reduction). */
 int sdm_transpose_bf16(const uint16_t* src, int64_t ld_src, int64_t src_bs0, int64_t src_bs1, int bdiv,
                        uint16_t* dst, int64_t ld_dst, int64_t dst_bs, int batch, int R, int Cc, sdm_stream_t s);
+
+/* ---- bf16 TRAINING path (BASELINE configs 4-5; reference analogue: fp16 autocast + GradScaler, train_diffusion.py:333,
+ * 358-364).  fp32 master weights, fp32 weight gradients and optimizer state; activations, activation gradients and the
+ * weight copies read by the contractions are bf16; all sums fp32.  Forward and data gradient run sdm_igemm_bf16 (the
+ * data gradient against a transposed weight copy, sdm_cast_bf16_t, with out_preact / dact_z / res pointing at bf16 rows);
+ * what follows is the rest of the backward.  Parity: the reference has no bf16 mode, gate = rel-L2 <= 2e-2 per gradient
+ * tensor against the fp32 oracle ("parity unpinned" for the rounding itself). */
+
+/* Weight gradient with bf16 operands and an fp32 result: same descriptor as sdm_wgrad, g.p0 / x.p0 / x.p1 point at bf16
+ * rows (pitches and strides in ELEMENTS, multiples of 8; rows 16-byte aligned and physically >= their channel count
+ * rounded up to 8; concat split a multiple of 8; no pending affine), dw / dbias fp32.  Both operands are K-major row
+ * tiles staged by LDS-DMA and read with the transposing LDS read ds_read_b64_tr_b16. */
+int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream);
+/* dst[t][c][r] = bf16(src[t][r][c]) for t < T: transposed bf16 weight copy (tap-major conv weights [tap][c_out][c_in] ->
+ * [tap][c_in][c_out]; Linear [O][K] -> [K][O] with T = 1). */
+int sdm_cast_bf16_t(const float* src, uint16_t* dst, int T, int R, int Cc, sdm_stream_t s);
+/* sdm_gn_adagn_bwd with dout / y / z / dz as bf16 rows (C %% 8 == 0, C <= 2048); sums, coefficients, dmod / dgamma / dbeta
+ * fp32; same zero-filled ws contract. */
+int sdm_gn_adagn_bwd_bf16(const uint16_t* dout, int64_t lddo, const uint16_t* y, int64_t ldy, const uint16_t* z, int64_t ldz,
+                          int images, int HW, int C, int groups, const float* gamma, const float* beta,
+                          const float* mod, int mod_nstride, const float* mean, const float* rstd,
+                          uint16_t* dz, int64_t lddz, float* dmod, float* dgamma, float* dbeta, float* ws, float* coef,
+                          sdm_stream_t s);
+/* Column-softmax backward: dS = scale * P * (dP - sum_i P*dP) per column; P bf16 [batch][S][ldp], dP fp32 [batch][S][lddp],
+ * dS bf16 [batch][S][ldds] with columns [S, ldds) zero-filled. */
+int sdm_col_softmax_bwd_bf16(const uint16_t* P, int64_t ldp, const float* dP, int64_t lddp, uint16_t* dS, int64_t ldds,
+                             int batch, int S, float scale, sdm_stream_t s);
+/* dx = silu'(z) * dy on contiguous bf16 data; out[c] += sum_r x[r][c] for bf16 rows (bias gradients, fp32 sums). */
+int sdm_silu_bwd_bf16(const uint16_t* dy, const uint16_t* z, uint16_t* dx, size_t n, sdm_stream_t s);
+int sdm_colsum_bf16(const uint16_t* x, int64_t ldx, int rows, int C, float* out, sdm_stream_t s);
+/* Edge-conv gradients with the NHWC side in bf16 (NCHW side, weights and weight gradients fp32): see sdm_stem_conv_wgrad,
+ * sdm_head_conv_dgrad, sdm_head_conv_wgrad. */
+int sdm_stem_conv_wgrad_bf16(const float* x_nchw, const uint16_t* g_nhwc, float* dw_tap, float* dbias, float* ws,
+                             int images, int Cin, int H, int W, int Cout, sdm_stream_t s);
+int sdm_head_conv_dgrad_bf16(const float* dy_nchw, const float* w_tap, uint16_t* dx_nhwc, const uint16_t* dact_z,
+                             int images, int Cin, int H, int W, int Cout, sdm_stream_t s);
+int sdm_head_conv_wgrad_bf16(const uint16_t* x_nhwc, const float* g_nchw, float* dw_tap, float* dbias, float* ws,
+                             int images, int Cin, int H, int W, int Cout, sdm_stream_t s);
 
 #ifdef __cplusplus
 }

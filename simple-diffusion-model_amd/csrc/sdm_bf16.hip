@@ -13,17 +13,6 @@
 
 #include "sdm_common.h"
 
-typedef unsigned short bf16_t;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {   // round to nearest even (v_cvt_pk_bf16_f32 on gfx950)
-  const __bf16 b = (__bf16)f;
-  return __builtin_bit_cast(bf16_t, b);
-}
-
 #define BKE 64   // reduction elements per K-step (128 bytes)
 #define ROWF 32  // floats per LDS tile row
 
@@ -276,8 +265,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
   const long long obo = b0 * d.o_bs0 + b1 * d.o_bs1;
   const long long rbo = b0 * d.r_bs0 + b1 * d.r_bs1;
   bf16_t* out16 = (bf16_t*)d.out;
+  bf16_t* pre16 = (bf16_t*)d.out_preact;
   const bf16_t* res16 = (const bf16_t*)d.res;
   const bf16_t* res216 = (const bf16_t*)d.res2;
+  const bf16_t* dz16 = (const bf16_t*)d.dact_z;
   if (L.splitk == 1 && L.vec_epi) {
     // Staged through LDS: the accumulator layout gives a lane ONE column and 16 scattered rows of a 32x32 tile, i.e.
     // 2-byte stores; the ring (no longer needed) is reused as an fp32 [BM][BN] tile so that every lane finishes 4
@@ -306,7 +297,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
       if (d.bias) bv = *(const f32x4*)(d.bias + col);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = sdm_act(v[q] * d.alpha + bv[q], d.act);
+      for (int q = 0; q < 4; ++q) v[q] = v[q] * d.alpha + bv[q];
+      if (pre16) {     // pre-activation copy for the backward (training)
+        u16x4 zo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zo[q] = f2bf(v[q]);
+        *(u16x4*)(pre16 + obo + orow * d.ldo + col) = zo;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = sdm_act(v[q], d.act);
       if (res16) {
         const u16x4 rv = *(const u16x4*)(res16 + rbo + orow * d.ldres + col);
 #pragma unroll
@@ -316,6 +315,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
         const u16x4 rv = *(const u16x4*)(res216 + orow * d.ldres2 + col);
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] += bf2f(rv[q]);
+      }
+      if (dz16 && (d.dact_ncols == 0 || col < d.dact_ncols)) {   // data gradient: times silu'(z) of the producer
+        const u16x4 zv = *(const u16x4*)(dz16 + orow * d.ldz + col);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] *= sdm_dsilu(bf2f(zv[q]));
       }
       if (L.out_f32) {
         *(f32x4*)(d.out + obo + orow * d.ldo + col) = v;
@@ -345,9 +349,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
           atomicAdd(&d.ws[((long long)blockIdx.z * L.out_rows + orow) * N + col], v);
           continue;
         }
-        v = sdm_act(v * d.alpha + bias, d.act);
+        v = v * d.alpha + bias;
+        if (pre16) pre16[obo + orow * d.ldo + col] = f2bf(v);
+        v = sdm_act(v, d.act);
         if (res16) v += bf2f(res16[rbo + orow * d.ldres + col]);
         if (res216) v += bf2f(res216[orow * d.ldres2 + col]);
+        if (dz16 && (d.dact_ncols == 0 || col < d.dact_ncols)) v *= sdm_dsilu(bf2f(dz16[orow * d.ldz + col]));
         if (L.out_f32) d.out[obo + orow * d.ldo + col] = v;
         else out16[obo + orow * d.ldo + col] = f2bf(v);
       }
@@ -369,9 +376,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_bf16_kernel(const sdm_ige
     const long long oo = b0 * d.o_bs0 + b1 * d.o_bs1 + orow * d.ldo + col;
     float v = d.ws[e] * d.alpha + (d.bias ? d.bias[col] : 0.f);
     d.ws[e] = 0.f;
+    if (d.out_preact) ((bf16_t*)d.out_preact)[oo] = f2bf(v);
     v = sdm_act(v, d.act);
     if (res16) v += bf2f(res16[b0 * d.r_bs0 + b1 * d.r_bs1 + orow * d.ldres + col]);
     if (res216) v += bf2f(res216[orow * d.ldres2 + col]);
+    if (d.dact_z && (d.dact_ncols == 0 || col < d.dact_ncols)) v *= sdm_dsilu(bf2f(((const bf16_t*)d.dact_z)[orow * d.ldz + col]));
     if (out_f32) d.out[oo] = v;
     else out16[oo] = f2bf(v);
   }
@@ -393,9 +402,8 @@ static int bf_validate(const sdm_igemm_desc* d, int out_f32) {
   SDM_CHECK_ARG(aligned16(d->b) && d->ldb % 8 == 0 && d->b_tap_stride % 8 == 0 && d->b_bs0 % 8 == 0 && d->b_bs1 % 8 == 0,
                 "igemm_bf16: B rows must be 16-byte aligned");
   SDM_CHECK_ARG(d->b_kmajor == 0, "igemm_bf16: K-major B is not supported (transpose the operand: sdm_transpose_bf16)");
-  SDM_CHECK_ARG(d->a.scale == nullptr && d->out_preact == nullptr && d->dact_z == nullptr,
-                "igemm_bf16: affine-on-load / pre-activation output / dact are fp32-path (training) features");
-  SDM_CHECK_ARG(!(out_f32 && (d->res || d->res2)), "igemm_bf16: fp32 output takes no residual");
+  SDM_CHECK_ARG(d->a.scale == nullptr, "igemm_bf16: no affine-on-load on bf16 rows (materialise it: sdm_affine_residual_bf16)");
+  SDM_CHECK_ARG(!(out_f32 && (d->res || d->res2 || d->out_preact)), "igemm_bf16: fp32 output takes no residual / pre-activation copy");
   SDM_CHECK_ARG(d->ostride >= 1 && d->sstride >= 1 && d->Ho > 0 && d->Wo > 0, "igemm_bf16: bad strides/output dims");
   SDM_CHECK_ARG(d->act >= 0 && d->act <= 2, "igemm_bf16: bad act");
   return SDM_OK;
@@ -492,7 +500,10 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
     L.vec_epi = d->N % 4 == 0 && al(d->out, 4 * esz) && d->ldo % 4 == 0 && d->o_bs0 % 4 == 0 && d->o_bs1 % 4 == 0 &&
                 (d->bias == nullptr || al(d->bias, 16)) &&
                 (d->res == nullptr || (al(d->res, 8) && d->ldres % 4 == 0 && d->r_bs0 % 4 == 0 && d->r_bs1 % 4 == 0)) &&
-                (d->res2 == nullptr || (al(d->res2, 8) && d->ldres2 % 4 == 0)) && !(noepi && noepi[0] == '0');
+                (d->res2 == nullptr || (al(d->res2, 8) && d->ldres2 % 4 == 0)) &&
+                (d->out_preact == nullptr || al(d->out_preact, 8)) &&
+                (d->dact_z == nullptr || (al(d->dact_z, 8) && d->ldz % 4 == 0 && d->dact_ncols % 4 == 0)) &&
+                !(noepi && noepi[0] == '0');
   }
   const int bm = kBfCfgs[cfg].bm, bn = kBfCfgs[cfg].bn;
   const int ntm = cdiv(d->M, bm);
@@ -546,7 +557,8 @@ extern "C" int sdm_cast_bf16(const float* src, uint16_t* dst, size_t n, sdm_stre
 template <int CIN>
 __global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, bf16_t* __restrict__ out,
-                                                             int images, int H, int W, int Cout, int act) {
+                                                             bf16_t* __restrict__ preact, int images, int H, int W, int Cout,
+                                                             int act) {
   constexpr int K = CIN * 9;
   __shared__ float patch[STEM_PIX_BF][K];
   const long long P = (long long)images * H * W;
@@ -577,18 +589,19 @@ __global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const float* __rest
       float a = b;
 #pragma unroll
       for (int k = 0; k < K; ++k) a = fmaf(patch[pi][k], wr[k], a);
+      if (preact) preact[p * Cout + co] = f2bf(a);
       out[p * Cout + co] = f2bf(sdm_act(a, act));
     }
   }
 }
 
-extern "C" int sdm_stem_conv_bf16(const float* x, const float* w, const float* bias, uint16_t* out, int images, int Cin,
-                                  int H, int W, int Cout, int act, sdm_stream_t s) {
+extern "C" int sdm_stem_conv_bf16(const float* x, const float* w, const float* bias, uint16_t* out, uint16_t* out_preact,
+                                  int images, int Cin, int H, int W, int Cout, int act, sdm_stream_t s) {
   SDM_CHECK_ARG(x && w && out && images > 0 && H > 0 && W > 0 && Cout > 0, "stem_conv_bf16: bad args");
   SDM_CHECK_ARG(Cin >= 1 && Cin <= 8, "stem_conv_bf16: Cin %d not in [1,8]", Cin);
   const long long P = (long long)images * H * W;
   const dim3 grid(cdiv(P, STEM_PIX_BF));
-#define STEM_BF(C) hipLaunchKernelGGL(stem_conv_bf16_kernel<C>, grid, dim3(256), 0, (hipStream_t)s, x, w, bias, out, images, H, W, Cout, act)
+#define STEM_BF(C) hipLaunchKernelGGL(stem_conv_bf16_kernel<C>, grid, dim3(256), 0, (hipStream_t)s, x, w, bias, out, out_preact, images, H, W, Cout, act)
   switch (Cin) {
     case 1: STEM_BF(1); break;
     case 2: STEM_BF(2); break;
@@ -666,7 +679,7 @@ __global__ __launch_bounds__(1024) void gn_affine_bf16_kernel(const bf16_t* __re
                                                               int groups, float eps, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ mod,
                                                               int mod_ns, float* __restrict__ scale, float* __restrict__ shift,
-                                                              int vec) {
+                                                              float* __restrict__ mean_o, float* __restrict__ rstd_o, int vec) {
   __shared__ double red[2][16];
   const int n = blockIdx.x / groups, g = blockIdx.x % groups;
   const int cpg = C / groups;
@@ -716,6 +729,10 @@ __global__ __launch_bounds__(1024) void gn_affine_bf16_kernel(const bf16_t* __re
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float mu = (float)mean;
+  if (threadIdx.x == 0 && mean_o) {      // the backward of the training path needs the statistics
+    mean_o[n * groups + g] = mu;
+    rstd_o[n * groups + g] = rstd;
+  }
   for (int c = threadIdx.x; c < cpg; c += 1024) {
     const int ch = g * cpg + c;
     const float ga = gamma[ch], be = beta[ch];
@@ -727,12 +744,12 @@ __global__ __launch_bounds__(1024) void gn_affine_bf16_kernel(const bf16_t* __re
 
 extern "C" int sdm_gn_affine_bf16(const uint16_t* y, int64_t ldy, int images, int HW, int C, int groups, float eps,
                                   const float* gamma, const float* beta, const float* mod, int mod_nstride, float* scale,
-                                  float* shift, sdm_stream_t s) {
-  SDM_CHECK_ARG(y && gamma && beta && scale && shift, "gn_affine_bf16: null pointer");
+                                  float* shift, float* mean, float* rstd, sdm_stream_t s) {
+  SDM_CHECK_ARG(y && gamma && beta && scale && shift && (mean == nullptr) == (rstd == nullptr), "gn_affine_bf16: null pointer");
   SDM_CHECK_ARG(images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_affine_bf16: C %d not divisible by groups %d", C, groups);
   const int vec = ((C / groups) % 4 == 0) && ldy % 4 == 0 && (((uintptr_t)y) & 7) == 0;
   hipLaunchKernelGGL(gn_affine_bf16_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, y, (long long)ldy, HW, C,
-                     groups, eps, gamma, beta, mod, mod_nstride, scale, shift, vec);
+                     groups, eps, gamma, beta, mod, mod_nstride, scale, shift, mean, rstd, vec);
   SDM_CHECK_LAUNCH("gn_affine_bf16");
   return SDM_OK;
 }

@@ -1,0 +1,532 @@
+// bf16 TRAINING path (BASELINE configs 4-5; reference analogue: fp16 autocast, train_diffusion.py:333,358-364).
+// fp32 master weights and fp32 weight gradients / optimizer; activations, activation gradients and the weight copies the
+// contractions read are bf16; every sum is fp32 (matrix-core accumulators, GroupNorm statistics, softmax, bias sums).
+//
+//   forward, data gradient : sdm_igemm_bf16 (sdm_bf16.hip) -- the data gradient contracts against a TRANSPOSED bf16 weight
+//                            copy [tap][c_in][c_out] (sdm_cast_bf16_t) so that both operands stay reduction-contiguous
+//   weight gradient        : wgrad_bf16_kernel below -- the reduction runs over PIXELS, so both operands are K-major
+//                            [pixel][channel] row tiles; they go global -> LDS by LDS-DMA exactly as they lie in HBM and the
+//                            matrix-core fragments (8 consecutive k per lane) are read with ds_read_b64_tr_b16, the gfx950
+//                            transposing LDS read (two per fragment), from an XOR-swizzled image that keeps them conflict-free
+//   pointwise              : GroupNorm/AdaGN backward, column-softmax backward, SiLU backward, edge-conv gradients on bf16 rows
+#include <stdlib.h>
+
+#include "sdm_common.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ float g_zero_chunk_wg[4];
+
+__device__ __forceinline__ int xcd_contiguous_wg(int bid, int total) {   // see sdm_igemm.hip
+  const int q = total >> 3, r = total & 7, x = bid & 7, i = bid >> 3;
+  return x < r ? x * (q + 1) + i : r * (q + 1) + (x - r) * q + i;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_wg() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct WgradBfLaunch {
+  sdm_wgrad_desc d;
+  int splitk, ntn, atomic_out;
+};
+
+#define BKP 64   // pixels per K-step
+
+// dw[tap][i][j] (+)= alpha * sum_p G[gpix(p,tap)][i] * X[xpix(p,tap)][j]      G, X: bf16 rows; dw: fp32
+//
+// LDS image of one operand stage: [BKP pixel rows][BT channels] bf16, row pitch 2*BT bytes, filled lane-linearly by
+// global_load_lds_dwordx4 (one wave-instruction = 1 KiB = 4 rows of 256 B at BT=128, 8 rows of 128 B at BT=64).  The
+// 16-byte chunk index is XOR-swizzled with f(k) on the per-lane SOURCE address and again on the read:
+//   BT=128: f(k) = (k&3)<<2      BT=64: f(k) = ((k>>1)&1)<<2
+// so that the 4 pixel rows x 64 bytes one 32-lane half of a ds_read_b64_tr_b16 touches fall into four different
+// quarters of the 256-byte bank line (conflict-free; unswizzled they are 4-way / 2-way).
+// Fragment of v_mfma_f32_32x32x16_bf16 (lane l: r=l&31, h=l>>5 holds k = 8h..8h+7 of channel r): two transposing reads;
+// in each, the 16-lane group (l>>4) covers pixel rows kb..kb+3 (kb = 16*kk + 8h + 4*rd) x channels c0+16*((l>>4)&1)..+15,
+// lane 4q+p of the group supplies the address of row kb+q, channels +4p..+4p+3, and receives channel (l&15)'s 4 rows.
+template <int BT, int NBUF>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradBfLaunch L) {
+  const sdm_wgrad_desc& d = L.d;
+  constexpr int TM = BT / 64, TN = BT / 64;     // 32x32 MFMA tiles per wave (waves 2x2)
+  constexpr int ROWB = 2 * BT;                  // bytes per LDS row
+  constexpr int CPR = BT / 8;                   // 16-byte chunks per row
+  constexpr int RPP = 256 / CPR;                // pixel rows per DMA pass of the 256 threads
+  constexpr int IT = BKP / RPP;                 // passes per operand per K-step
+  constexpr int TILEB = BKP * ROWB;             // bytes per operand stage
+  constexpr int G = 2 * IT;
+  constexpr int PD = NBUF - 1;
+  extern __shared__ __align__(16) char smem_wg[];
+  char* As = smem_wg;
+  char* Bs = smem_wg + NBUF * TILEB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
+  const int ntiles_ = gridDim.x / L.splitk;
+  const int wg_ = xcd_contiguous_wg(blockIdx.x, gridDim.x);
+  const int ks = wg_ / ntiles_, tile_ = wg_ - ks * ntiles_;
+  const int tile_n = tile_ % L.ntn, tile_m = tile_ / L.ntn;
+  const int tp = blockIdx.y;
+  const int m0 = tile_m * BT, n0 = tile_n * BT;
+  const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
+  const bf16_t* g0 = (const bf16_t*)d.g.p0 + b0 * d.g_bs0 + b1 * d.g_bs1;
+  const bf16_t* x0 = (const bf16_t*)d.x.p0 + b0 * d.x_bs0 + b1 * d.x_bs1;
+  const bf16_t* x1 = (const bf16_t*)d.x.p1;
+  const bf16_t* zero = (const bf16_t*)g_zero_chunk_wg;
+  const int HW = d.Hk * d.Wk;
+  const long long P = (long long)d.images * HW;
+  const int T = (int)((P + BKP - 1) / BKP);
+  const int it0 = (int)((long long)T * ks / L.splitk), it1 = (int)((long long)T * (ks + 1) / L.splitk);
+  const int gdy = d.g_dy[tp], gdx = d.g_dx[tp], xdy = d.x_dy[tp], xdx = d.x_dx[tp];
+  // DMA role of this thread: pixel rows (tid / CPR) + RPP*i, physical chunk slot tid % CPR -> logical chunk slot ^ f(row)
+  const int drow = tid / CPR;
+  const int fk = BT == 128 ? ((drow & 3) << 2) : (((drow >> 1) & 1) << 2);
+  const int lchunk = (tid % CPR) ^ fk;
+  const int cm = m0 + 8 * lchunk, cn = n0 + 8 * lchunk;
+  const bool gch = cm < ((d.M + 7) & ~7), xch = cn < ((d.N + 7) & ~7);
+  const bool xsrc0 = cn < d.x.csplit;
+  const bool do_bias = d.dbias != nullptr && tile_n == 0 && tp == 0;   // block-uniform
+  float bacc = 0.f;
+
+  int pn[IT], py[IT], px[IT];
+  const int adv_x = BKP % d.Wk, qw = BKP / d.Wk;
+  const int adv_y = qw % d.Hk, adv_n = qw / d.Hk;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const long long p = (long long)it0 * BKP + drow + RPP * i;
+    const int n = (int)(p / HW), rem = (int)(p - (long long)n * HW);
+    pn[i] = n;
+    py[i] = rem / d.Wk;
+    px[i] = rem - py[i] * d.Wk;
+  }
+
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  int issued = it0;
+  auto issue_next = [&]() {
+    if (issued < it1) {
+      const int buf = (issued - it0) % NBUF;
+      char* Ad = As + buf * TILEB + __builtin_amdgcn_readfirstlane(wave) * 1024;
+      char* Bd = Bs + buf * TILEB + __builtin_amdgcn_readfirstlane(wave) * 1024;
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int n = pn[i], y = py[i], x = px[i];
+        const bool in = n < d.images;
+        const int gy = y * d.g_stride + gdy, gx = x * d.g_stride + gdx;
+        const int xy = y * d.x_stride + xdy, xx = x * d.x_stride + xdx;
+        const bool gu = in && gch && (unsigned)gy < (unsigned)d.g.H && (unsigned)gx < (unsigned)d.g.W;
+        const bool xu = in && xch && (unsigned)xy < (unsigned)d.x.H && (unsigned)xx < (unsigned)d.x.W;
+        const long long xrow = ((long long)n * d.x.H + xy) * d.x.W + xx;
+        const bf16_t* gq = g0 + (((long long)n * d.g.H + gy) * d.g.W + gx) * d.g.ld0 + cm;
+        const bf16_t* xq = xsrc0 ? x0 + xrow * d.x.ld0 + cn : x1 + xrow * d.x.ld1 + (cn - d.x.csplit);
+        gq = gu ? gq : zero;
+        xq = xu ? xq : zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr)gq, (lds_ptr)(Ad + i * RPP * ROWB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)xq, (lds_ptr)(Bd + i * RPP * ROWB), 16, 0, 0);
+        int nx = x + adv_x, ny = y + adv_y, nn = n + adv_n;
+        if (nx >= d.Wk) { nx -= d.Wk; ny += 1; }
+        if (ny >= d.Hk) { ny -= d.Hk; nn += 1; }
+        px[i] = nx; py[i] = ny; pn[i] = nn;
+      }
+    }
+    ++issued;
+  };
+
+  // transposing-read role of this lane (constant over K-steps): row q of its group's 4-row block, channel quad p
+  const int i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, chalf = (lane >> 4) & 1;
+  const int fq = BT == 128 ? (q << 2) : ((q >> 1) << 2);
+  int aoff[TM], boff[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int col = wm * TM * 32 + i * 32 + 16 * chalf + 4 * p4;
+    aoff[i] = (8 * h + q) * ROWB + (((col >> 3) ^ fq) << 4) + ((col & 4) << 1);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * TN * 32 + j * 32 + 16 * chalf + 4 * p4;
+    boff[j] = (8 * h + q) * ROWB + (((col >> 3) ^ fq) << 4) + ((col & 4) << 1);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  typedef __attribute__((address_space(3))) s16x4* tr_ptr;
+#pragma unroll
+  for (int pp = 0; pp < PD; ++pp) issue_next();
+  for (int it = it0; it < it1; ++it) {
+    const int buf = (it - it0) % NBUF;
+    const int younger = (it1 - 1 - it) < (PD - 1) ? (it1 - 1 - it) : (PD - 1);
+    if (younger >= 2) wait_vmcnt_wg<2 * G>();
+    else if (younger == 1) wait_vmcnt_wg<G>();
+    else wait_vmcnt_wg<0>();
+    __builtin_amdgcn_s_barrier();
+    issue_next();
+    const char* Ab = As + buf * TILEB;
+    const char* Bb = Bs + buf * TILEB;
+    if (do_bias && tid < BT) {   // column sums of the gradient tile (bias gradient); channel tid
+      float a = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < BKP; ++k) {
+        const int f = BT == 128 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2);
+        a += bf2f(*(const bf16_t*)(Ab + k * ROWB + (((tid >> 3) ^ f) << 4) + ((tid & 7) << 1)));
+      }
+      bacc += a;
+    }
+#pragma unroll
+    for (int kk = 0; kk < BKP / 16; ++kk) {
+      s16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Ab + aoff[i] + (kk * 16) * ROWB));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Ab + aoff[i] + (kk * 16 + 4) * ROWB));
+        af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Bb + boff[j] + (kk * 16) * ROWB));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Bb + boff[j] + (kk * 16 + 4) * ROWB));
+        bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                              __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+    }
+  }
+  if (do_bias && tid < BT && m0 + tid < d.M) atomicAdd(&d.dbias[m0 + tid], bacc);
+
+  float* dw = d.dw + b0 * d.w_bs0 + b1 * d.w_bs1 + (long long)d.tap_w[tp] * d.w_tap_stride;
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + l31;
+      if (col >= d.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= d.M) continue;
+        float* o = dw + (long long)row * d.ldw + col;
+        const float v = acc[i][j][r] * d.alpha;
+        if (L.atomic_out) atomicAdd(o, v);
+        else *o = v;
+      }
+    }
+}
+
+template <int BT, int NBUF>
+static int launch_wgrad_bf16(const WgradBfLaunch& L, int ntm, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * NBUF * BKP * 2 * BT;
+  dim3 grid(ntm * L.ntn * L.splitk, L.d.ntaps, L.d.batch);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)wgrad_bf16_kernel<BT, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  {
+    const double px = (double)L.d.images;
+    const double g_b = px * L.d.g.H * L.d.g.W * L.d.M, x_b = px * L.d.x.H * L.d.x.W * L.d.N, w_b = (double)L.d.M * L.d.N * L.d.ntaps;
+    sdm_prof_shape(L.d.M, L.d.N, (int)((long)L.d.images * L.d.Hk * L.d.Wk), L.d.ntaps, L.splitk,
+                   L.d.batch * (2.0 * (g_b + x_b) + 4.0 * w_b));
+  }
+  sdm_prof_pre(st);
+  hipLaunchKernelGGL((wgrad_bf16_kernel<BT, NBUF>), grid, dim3(256), lds, st, L);
+  sdm_prof_post(st, BT == 128 ? 3 : 4, 2.0 * L.d.M * L.d.N * (double)L.d.images * L.d.Hk * L.d.Wk * L.d.ntaps * L.d.batch);
+  SDM_CHECK_LAUNCH("wgrad_bf16");
+  return SDM_OK;
+}
+
+__global__ void zero_rows_f32_kernel(float* p, long long rows, int cols, long long ld) {
+  const long long total = rows * cols;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long r = e / cols;
+    p[r * ld + (e - r * cols)] = 0.f;
+  }
+}
+
+extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
+  SDM_CHECK_ARG(d != nullptr, "wgrad_bf16: null desc");
+  SDM_CHECK_ARG(d->M > 0 && d->N > 0 && d->images > 0 && d->Hk > 0 && d->Wk > 0, "wgrad_bf16: bad dims");
+  SDM_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= SDM_MAX_TAPS, "wgrad_bf16: ntaps");
+  SDM_CHECK_ARG(d->g.p0 && d->x.p0 && d->dw, "wgrad_bf16: null operand");
+  SDM_CHECK_ARG(d->batch >= 1 && d->bdiv >= 1, "wgrad_bf16: bad batch");
+  SDM_CHECK_ARG(d->g.p1 == nullptr && d->g.scale == nullptr && d->x.scale == nullptr,
+                "wgrad_bf16: gradient rows cannot be concat/affine, activation rows carry no pending affine");
+  SDM_CHECK_ARG(d->x.p1 != nullptr || d->x.csplit >= d->N, "wgrad_bf16: csplit < N without second source");
+  SDM_CHECK_ARG(d->x.p1 == nullptr || d->x.csplit % 8 == 0, "wgrad_bf16: concat split must be a multiple of 8");
+  SDM_CHECK_ARG(d->dbias == nullptr || (d->g_stride == 1 && d->g_dy[0] == 0 && d->g_dx[0] == 0 && d->batch == 1),
+                "wgrad_bf16: fused bias gradient needs plain gradient rows");
+  // rows are read in whole 16-byte chunks of 8 channels: pitches / batch strides multiples of 8 elements, and each row
+  // must physically hold its channel count rounded up to 8 (attention probabilities are padded like that)
+  SDM_CHECK_ARG(aligned16(d->g.p0) && d->g.ld0 % 8 == 0 && d->g_bs0 % 8 == 0 && d->g_bs1 % 8 == 0 && d->g.ld0 >= ((d->M + 7) & ~7),
+                "wgrad_bf16: gradient rows must be 16-byte aligned with pitch >= M rounded up to 8");
+  SDM_CHECK_ARG(aligned16(d->x.p0) && d->x.ld0 % 8 == 0 && d->x_bs0 % 8 == 0 && d->x_bs1 % 8 == 0 &&
+                    (d->x.p1 == nullptr || (aligned16(d->x.p1) && d->x.ld1 % 8 == 0)) &&
+                    (d->x.p1 != nullptr || d->x.ld0 >= ((d->N + 7) & ~7)),
+                "wgrad_bf16: activation rows must be 16-byte aligned with pitch >= N rounded up to 8");
+  SDM_CHECK_ARG(d->x.p1 == nullptr || d->N % 8 == 0, "wgrad_bf16: concatenated rows need N %% 8 == 0");
+  hipStream_t st = (hipStream_t)stream;
+  WgradBfLaunch L;
+  L.d = *d;
+  const long P = (long)d->images * d->Hk * d->Wk;
+  const int T = cdiv(P, BKP);
+  // 128x128 tiles whenever the problem can feed them (the 64x64 form is LDS-read bound: 4 transposing reads per MFMA)
+  const long blocks128 = (long)cdiv(d->M, 128) * cdiv(d->N, 128) * d->ntaps * d->batch;
+  const bool big = d->M > 64 && d->N > 64 && (blocks128 >= 128 || (long)T * blocks128 >= 8L * 256);
+  const int bt = big ? 128 : 64;
+  const int ntm = cdiv(d->M, bt);
+  L.ntn = cdiv(d->N, bt);
+  const long blocks = (long)ntm * L.ntn * d->ntaps * d->batch;
+  int sk = 1;
+  if (blocks < 512 && T >= 8) {
+    sk = (int)((768 + blocks - 1) / blocks);
+    if (sk > T / 4) sk = T / 4;
+    if (sk > 128) sk = 128;
+    if (sk < 1) sk = 1;
+  }
+  static const char* force = getenv("SDM_WGRAD_BF16_FORCE");   // "bt,splitk" tuning override
+  int fbt = 0, fsk = 0;
+  if (force && sscanf(force, "%d,%d", &fbt, &fsk) == 2) {
+    if (fsk >= 1 && fsk <= T) sk = fsk;
+  }
+  L.splitk = sk;
+  L.atomic_out = (sk > 1 || d->accumulate == 1) ? 1 : 0;
+  if (sk > 1 && d->accumulate == 0) {
+    for (int b = 0; b < d->batch; ++b)
+      for (int t = 0; t < d->ntaps; ++t) {
+        float* p = d->dw + (b / d->bdiv) * d->w_bs0 + (b % d->bdiv) * d->w_bs1 + (long long)d->tap_w[t] * d->w_tap_stride;
+        hipLaunchKernelGGL(zero_rows_f32_kernel, dim3(cdiv((long)d->M * d->N, 1024)), dim3(256), 0, st, p, (long long)d->M, d->N,
+                           (long long)d->ldw);
+        SDM_CHECK_LAUNCH("zero_rows");
+      }
+  }
+  const bool use128 = fbt == 128 ? true : (fbt == 64 ? false : big);
+  if (use128 != big) {   // forced tile: recompute the tile counts
+    const int b2 = use128 ? 128 : 64;
+    L.ntn = cdiv(d->N, b2);
+    return use128 ? launch_wgrad_bf16<128, 2>(L, cdiv(d->M, b2), st) : launch_wgrad_bf16<64, 3>(L, cdiv(d->M, b2), st);
+  }
+  return big ? launch_wgrad_bf16<128, 2>(L, ntm, st) : launch_wgrad_bf16<64, 3>(L, ntm, st);
+}
+
+// --------------------------------------------------------------------------------------------
+// dst[t][c][r] = bf16(src[t][r][c]): the transposed bf16 weight copy the data gradient contracts against
+// (tap-major conv weights [tap][c_out][c_in] -> [tap][c_in][c_out]; linear weights [O][K] -> [K][O] with T = 1)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int R, int Cc) {
+  __shared__ float tile[64][65];
+  const float* s = src + (long long)blockIdx.z * R * Cc;
+  bf16_t* o = dst + (long long)blockIdx.z * R * Cc;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < Cc) ? s[(long long)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < Cc && r < R) o[(long long)c * R + r] = f2bf(tile[tx][i]);
+  }
+}
+
+extern "C" int sdm_cast_bf16_t(const float* src, uint16_t* dst, int T, int R, int Cc, sdm_stream_t s) {
+  SDM_CHECK_ARG(src && dst && T > 0 && R > 0 && Cc > 0, "cast_bf16_t: bad args");
+  hipLaunchKernelGGL(cast_bf16_t_kernel, dim3(cdiv(Cc, 64), cdiv(R, 64), T), dim3(256), 0, (hipStream_t)s, src, dst, R, Cc);
+  SDM_CHECK_LAUNCH("cast_bf16_t");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// AdaGN backward on bf16 rows (fp32 sums / coefficients; same ws / coef contract as sdm_gn_adagn_bwd).
+// --------------------------------------------------------------------------------------------
+// 8 channels per lane (C % 8 == 0, C <= 2048); partials meet in LDS, one atomic pair per channel per workgroup
+__global__ __launch_bounds__(256) void gn_bwd_sums_bf16_kernel(const bf16_t* __restrict__ dout, long long lddo,
+                                                               const bf16_t* __restrict__ y, long long ldy, int HW, int C,
+                                                               int rows_per_block, float* __restrict__ ws) {
+  __shared__ float part[2][256][8];
+  const int n = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > HW) r1 = HW;
+  const int q = C >> 3;                  // lanes per row
+  const int rl = threadIdx.x / q, cl = threadIdx.x - rl * q;
+  const int RL = 256 / q;                // rows in flight
+  float s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  if (rl < RL) {
+    for (int r = r0 + rl; r < r1; r += RL) {
+      const long long row = (long long)n * HW + r;
+      const u16x8 dv = *(const u16x8*)(dout + row * lddo + cl * 8);
+      const u16x8 yv = *(const u16x8*)(y + row * ldy + cl * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float dd = bf2f(dv[k]);
+        s1[k] += dd;
+        s2[k] = fmaf(dd, bf2f(yv[k]), s2[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    part[0][threadIdx.x][k] = s1[k];
+    part[1][threadIdx.x][k] = s2[k];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c >> 3, k = c & 7;
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < RL; ++j) {
+      a += part[0][j * q + g][k];
+      b += part[1][j * q + g][k];
+    }
+    atomicAdd(&ws[((long long)n * C + c) * 2 + 0], a);
+    atomicAdd(&ws[((long long)n * C + c) * 2 + 1], b);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_bf16_kernel(const bf16_t* __restrict__ dout, long long lddo,
+                                                                const bf16_t* __restrict__ y, long long ldy,
+                                                                const bf16_t* __restrict__ z, long long ldz,
+                                                                const float* __restrict__ coef, bf16_t* __restrict__ dz,
+                                                                long long lddz, long long rows, int HW, int C) {
+  const int C8 = C >> 3;
+  const long long total = rows * C8;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long r = e / C8;
+    const int c = (int)(e - r * C8) * 8;
+    const int n = (int)(r / HW);
+    const float* k = coef + (long long)n * 3 * C + c;
+    const u16x8 dv = *(const u16x8*)(dout + r * lddo + c);
+    const u16x8 yv = *(const u16x8*)(y + r * ldy + c);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = k[i] * bf2f(dv[i]) + k[C + i] * bf2f(yv[i]) + k[2 * C + i];
+    if (z) {
+      const u16x8 zv = *(const u16x8*)(z + r * ldz + c);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= sdm_dsilu(bf2f(zv[i]));
+    }
+    u16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
+    *(u16x8*)(dz + r * lddz + c) = o;
+  }
+}
+
+// coefficient pass: dtype-independent (works on the fp32 sums); kernel and launcher live in sdm_pointwise.hip
+int sdm_launch_gn_bwd_coef(float* ws, int images, int HW, int C, int groups, const float* gamma, const float* beta,
+                           const float* mod, int mod_ns, const float* mean, const float* rstd, float* coef, float* dmod,
+                           float* dgamma, float* dbeta, hipStream_t st);
+
+extern "C" int sdm_gn_adagn_bwd_bf16(const uint16_t* dout, int64_t lddo, const uint16_t* y, int64_t ldy, const uint16_t* z,
+                                     int64_t ldz, int images, int HW, int C, int groups, const float* gamma,
+                                     const float* beta, const float* mod, int mod_nstride, const float* mean,
+                                     const float* rstd, uint16_t* dz, int64_t lddz, float* dmod, float* dgamma, float* dbeta,
+                                     float* ws, float* coef, sdm_stream_t s) {
+  SDM_CHECK_ARG(dout && y && gamma && beta && mean && rstd && dz && ws && coef, "gn_adagn_bwd_bf16: null pointer");
+  SDM_CHECK_ARG(images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_adagn_bwd_bf16: bad dims");
+  SDM_CHECK_ARG(C % 8 == 0 && C <= 2048 && lddo % 8 == 0 && ldy % 8 == 0 && lddz % 8 == 0 && (z == nullptr || ldz % 8 == 0) &&
+                    aligned16(dout) && aligned16(y) && aligned16(dz) && (z == nullptr || aligned16(z)) && aligned16(coef),
+                "gn_adagn_bwd_bf16: rows must be 16-byte aligned, C a multiple of 8 (<= 2048)");
+  hipStream_t st = (hipStream_t)s;
+  int rpb = (HW + 63) / 64;
+  if (rpb < 8) rpb = 8;
+  hipLaunchKernelGGL(gn_bwd_sums_bf16_kernel, dim3(cdiv(HW, rpb), images), dim3(256), 0, st, dout, (long long)lddo, y,
+                     (long long)ldy, HW, C, rpb, ws);
+  SDM_CHECK_LAUNCH("gn_bwd_sums_bf16");
+  int rc = sdm_launch_gn_bwd_coef(ws, images, HW, C, groups, gamma, beta, mod, mod_nstride, mean, rstd, coef, dmod, dgamma,
+                                  dbeta, st);
+  if (rc != SDM_OK) return rc;
+  const long long rows = (long long)images * HW;
+  const long long work = rows * (C / 8);
+  int grid = (int)((work + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(gn_bwd_apply_bf16_kernel, dim3(grid), dim3(256), 0, st, dout, (long long)lddo, y, (long long)ldy, z,
+                     (long long)ldz, coef, dz, (long long)lddz, rows, HW, C);
+  SDM_CHECK_LAUNCH("gn_bwd_apply_bf16");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// column-softmax backward: dS[i][j] = scale * P[i][j] * (dP[i][j] - sum_i P[i][j] dP[i][j]);  P bf16, dP fp32 -> dS bf16;
+// dS columns [S, ldds) are zero-filled (reduction padding of the contractions that follow).
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void col_softmax_bwd_bf16_kernel(const bf16_t* __restrict__ p, long long ldp,
+                                                                   const float* __restrict__ dp, long long lddp,
+                                                                   bf16_t* __restrict__ ds, long long ldds, int S, float scale) {
+  __shared__ float sd[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const bf16_t* pb = p + (long long)blockIdx.y * S * ldp;
+  const float* dpb = dp + (long long)blockIdx.y * S * lddp;
+  bf16_t* dsb = ds + (long long)blockIdx.y * S * ldds;
+  float dot = 0.f;
+  if (j < S)
+    for (int i = wave; i < S; i += 4) dot = fmaf(bf2f(pb[(long long)i * ldp + j]), dpb[(long long)i * lddp + j], dot);
+  sd[wave][lane] = dot;
+  __syncthreads();
+  dot = sd[0][lane] + sd[1][lane] + sd[2][lane] + sd[3][lane];
+  if (j < S) {
+    for (int i = wave; i < S; i += 4)
+      dsb[(long long)i * ldds + j] = f2bf(scale * bf2f(pb[(long long)i * ldp + j]) * (dpb[(long long)i * lddp + j] - dot));
+  } else if (j < ldds) {
+    for (int i = wave; i < S; i += 4) dsb[(long long)i * ldds + j] = 0;
+  }
+}
+
+extern "C" int sdm_col_softmax_bwd_bf16(const uint16_t* P, int64_t ldp, const float* dP, int64_t lddp, uint16_t* dS,
+                                        int64_t ldds, int batch, int S, float scale, sdm_stream_t s) {
+  SDM_CHECK_ARG(P && dP && dS && batch > 0 && S > 0 && ldp >= S && lddp >= S && ldds >= S, "col_softmax_bwd_bf16: bad args");
+  hipLaunchKernelGGL(col_softmax_bwd_bf16_kernel, dim3(cdiv(ldds, 64), batch), dim3(256), 0, (hipStream_t)s, P, (long long)ldp,
+                     dP, (long long)lddp, dS, (long long)ldds, S, scale);
+  SDM_CHECK_LAUNCH("col_softmax_bwd_bf16");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// elementwise / reductions on bf16 rows
+// --------------------------------------------------------------------------------------------
+__global__ void silu_bwd_bf16_kernel(const bf16_t* dy, const bf16_t* z, bf16_t* dx, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    dx[i] = f2bf(bf2f(dy[i]) * sdm_dsilu(bf2f(z[i])));
+}
+extern "C" int sdm_silu_bwd_bf16(const uint16_t* dy, const uint16_t* z, uint16_t* dx, size_t n, sdm_stream_t s) {
+  SDM_CHECK_ARG(dy && z && dx && n > 0, "silu_bwd_bf16: bad args");
+  size_t grid = (n + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(silu_bwd_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)s, dy, z, dx, n);
+  SDM_CHECK_LAUNCH("silu_bwd_bf16");
+  return SDM_OK;
+}
+
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long long ldx, long long rows, int C,
+                                                          int rows_per_block, float* __restrict__ out) {
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (long long r = r0; r < r1; ++r) a += bf2f(x[r * ldx + c]);
+    atomicAdd(&out[c], a);
+  }
+}
+extern "C" int sdm_colsum_bf16(const uint16_t* x, int64_t ldx, int rows, int C, float* out, sdm_stream_t s) {
+  SDM_CHECK_ARG(x && out && rows > 0 && C > 0, "colsum_bf16: bad args");
+  int rpb = (rows + 1023) / 1024;
+  if (rpb < 4) rpb = 4;
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)s, x, (long long)ldx, (long long)rows,
+                     C, rpb, out);
+  SDM_CHECK_LAUNCH("colsum_bf16");
+  return SDM_OK;
+}

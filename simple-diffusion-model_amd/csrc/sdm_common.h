@@ -10,6 +10,17 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// bf16 storage helpers (bit patterns travel as unsigned short)
+typedef unsigned short bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {   // round to nearest even (v_cvt_pk_bf16_f32 on gfx950)
+  const __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+
 int sdm_set_error(int code, const char* fmt, ...);
 
 #define SDM_CHECK_ARG(cond, ...)                         \

@@ -10,6 +10,12 @@
 #define STEM_PIX 32
 #define EDGE_MAXC 8
 
+// NHWC-side element type of the edge kernels: float (fp32 path) or bf16_t (bf16 storage / training path)
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16_t* p, float v) { *p = f2bf(v); }
+
 #define EDGE_DISPATCH(C, CALL)                                   \
   switch (C) {                                                   \
     case 1: { constexpr int EC = 1; CALL; } break;               \
@@ -86,8 +92,8 @@ extern "C" int sdm_stem_conv(const float* x, const float* w, const float* bias, 
 // stem weight/bias gradient: dw[tap][co][ci] = sum_p g[p][co] * x[n][ci][p+d(tap)] ; db[co] = sum_p g[p][co]
 // each workgroup walks pix_per_block pixels; thread = output channel, CIN*9+1 register accumulators; partials are
 // written to a scratch slab [block][K+1][Cout] and folded by stem_wgrad_reduce_kernel (no atomics).
-template <int CIN>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
+template <int CIN, typename TG>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const TG* __restrict__ g,
                                                          float* __restrict__ slab, int images, int H, int W, int Cout,
                                                          int pix_per_block) {
   constexpr int K = CIN * 9;
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         for (int pi = 0; pi < STEM_PIX; ++pi) {
           const long long p = pb + q + pi;
           if (p >= P || q + pi >= pix_per_block) break;
-          const float gv = g[p * Cout + co];
+          const float gv = ldf(g + p * Cout + co);
           accb += gv;
 #pragma unroll
           for (int k = 0; k < K; ++k) acc[k] = fmaf(gv, patch[pi][k], acc[k]);
@@ -146,20 +152,30 @@ extern "C" size_t sdm_edge_wgrad_workspace_bytes(int Cin_or_Cout_small, int C) {
   return (size_t)EDGE_WGRAD_BLOCKS * (9 * Cin_or_Cout_small + 1) * C * sizeof(float);
 }
 
-extern "C" int sdm_stem_conv_wgrad(const float* x, const float* g, float* dw, float* db, float* ws, int images, int Cin,
-                                   int H, int W, int Cout, sdm_stream_t s) {
+template <typename TG>
+static int stem_conv_wgrad_impl(const float* x, const TG* g, float* dw, float* db, float* ws, int images, int Cin, int H, int W,
+                                int Cout, sdm_stream_t s) {
   SDM_CHECK_ARG(x && g && dw && ws && Cin >= 1 && Cin <= EDGE_MAXC, "stem_conv_wgrad: bad args");
   hipStream_t st = (hipStream_t)s;
   const long long P = (long long)images * H * W;
   int ppb = (int)((P + EDGE_WGRAD_BLOCKS - 1) / EDGE_WGRAD_BLOCKS);
   ppb = ((ppb + STEM_PIX - 1) / STEM_PIX) * STEM_PIX;
   const int nb = cdiv(P, ppb);
-  EDGE_DISPATCH(Cin, hipLaunchKernelGGL(stem_wgrad_kernel<EC>, dim3(nb), dim3(256), 0, st, x, g, ws, images, H, W, Cout, ppb));
+  EDGE_DISPATCH(Cin, hipLaunchKernelGGL((stem_wgrad_kernel<EC, TG>), dim3(nb), dim3(256), 0, st, x, g, ws, images, H, W, Cout, ppb));
   SDM_CHECK_LAUNCH("stem_conv_wgrad");
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv((long)(9 * Cin + 1) * Cout, 256)), dim3(256), 0, st, ws, dw, db, nb,
                      Cin, Cout);
   SDM_CHECK_LAUNCH("stem_wgrad_reduce");
   return SDM_OK;
+}
+
+extern "C" int sdm_stem_conv_wgrad(const float* x, const float* g, float* dw, float* db, float* ws, int images, int Cin,
+                                   int H, int W, int Cout, sdm_stream_t s) {
+  return stem_conv_wgrad_impl<float>(x, g, dw, db, ws, images, Cin, H, W, Cout, s);
+}
+extern "C" int sdm_stem_conv_wgrad_bf16(const float* x, const uint16_t* g, float* dw, float* db, float* ws, int images, int Cin,
+                                        int H, int W, int Cout, sdm_stream_t s) {
+  return stem_conv_wgrad_impl<bf16_t>(x, g, dw, db, ws, images, Cin, H, W, Cout, s);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -209,9 +225,9 @@ extern "C" int sdm_head_conv(const float* x, const float* w, const float* bias, 
 }
 
 // dx[p][c] = silu'(z[p][c]) * sum_tap sum_co dy[n][co][p - d(tap)] * w[tap][co][c]
-template <int COUT>
+template <int COUT, typename T>
 __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                         float* __restrict__ dx, const float* __restrict__ z, int images,
+                                                         T* __restrict__ dx, const T* __restrict__ z, int images,
                                                          int Cin, int H, int W) {
   __shared__ float g[4][9 * EDGE_MAXC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -236,29 +252,39 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
         float a = 0.f;
 #pragma unroll
         for (int e = 0; e < 9 * COUT; ++e) a = fmaf(g[wave][e], w[(long long)e * Cin + c], a);
-        if (z) a *= sdm_dsilu(z[p * Cin + c]);
-        dx[p * Cin + c] = a;
+        if (z) a *= sdm_dsilu(ldf(z + p * Cin + c));
+        stf(dx + p * Cin + c, a);
       }
     }
   }
 }
 
-extern "C" int sdm_head_conv_dgrad(const float* dy, const float* w, float* dx, const float* z, int images, int Cin, int H,
-                                   int W, int Cout, sdm_stream_t s) {
+template <typename T>
+static int head_conv_dgrad_impl(const float* dy, const float* w, T* dx, const T* z, int images, int Cin, int H, int W, int Cout,
+                                sdm_stream_t s) {
   SDM_CHECK_ARG(dy && w && dx && Cout >= 1 && Cout <= EDGE_MAXC, "head_conv_dgrad: bad args");
   const long long P = (long long)images * H * W;
   int grid = (int)((P + 3) / 4);
   if (grid > 8192) grid = 8192;
-  EDGE_DISPATCH(Cout, hipLaunchKernelGGL(head_dgrad_kernel<EC>, dim3(grid), dim3(256), 0, (hipStream_t)s, dy, w, dx, z,
+  EDGE_DISPATCH(Cout, hipLaunchKernelGGL((head_dgrad_kernel<EC, T>), dim3(grid), dim3(256), 0, (hipStream_t)s, dy, w, dx, z,
                                          images, Cin, H, W));
   SDM_CHECK_LAUNCH("head_conv_dgrad");
   return SDM_OK;
 }
 
+extern "C" int sdm_head_conv_dgrad(const float* dy, const float* w, float* dx, const float* z, int images, int Cin, int H,
+                                   int W, int Cout, sdm_stream_t s) {
+  return head_conv_dgrad_impl<float>(dy, w, dx, z, images, Cin, H, W, Cout, s);
+}
+extern "C" int sdm_head_conv_dgrad_bf16(const float* dy, const float* w, uint16_t* dx, const uint16_t* z, int images, int Cin,
+                                        int H, int W, int Cout, sdm_stream_t s) {
+  return head_conv_dgrad_impl<bf16_t>(dy, w, dx, z, images, Cin, H, W, Cout, s);
+}
+
 // dw[tap][co][c] = sum_p g[n][co][p] * x[p + d(tap)][c]; threads over c, COUT*9 register accumulators each,
 // partials to a slab [block][tap*COUT+co | 9*COUT (unused)][Cin]; bias sums by the first COUT threads.
-template <int COUT>
-__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
+template <int COUT, typename TX>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const TX* __restrict__ x, const float* __restrict__ g,
                                                          float* __restrict__ slab, float* __restrict__ db, int images,
                                                          int Cin, int H, int W, int pix_per_block) {
   const long long P = (long long)images * H * W;
@@ -279,7 +305,7 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
       for (int tap = 0; tap < 9; ++tap) {
         const int sy = y + tap / 3 - 1, sx = xx + tap % 3 - 1;
         if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) continue;
-        const float xv = x[(((long long)n * H + sy) * W + sx) * Cin + c];
+        const float xv = ldf(x + (((long long)n * H + sy) * W + sx) * Cin + c);
 #pragma unroll
         for (int co = 0; co < COUT; ++co) acc[tap * COUT + co] = fmaf(gv[co], xv, acc[tap * COUT + co]);
       }
@@ -309,20 +335,30 @@ __global__ void head_wgrad_reduce_kernel(const float* __restrict__ slab, float* 
   dw[e] += a;
 }
 
-extern "C" int sdm_head_conv_wgrad(const float* x, const float* g, float* dw, float* db, float* ws, int images, int Cin,
-                                   int H, int W, int Cout, sdm_stream_t s) {
+template <typename TX>
+static int head_conv_wgrad_impl(const TX* x, const float* g, float* dw, float* db, float* ws, int images, int Cin, int H, int W,
+                                int Cout, sdm_stream_t s) {
   SDM_CHECK_ARG(x && g && dw && ws && Cout >= 1 && Cout <= EDGE_MAXC, "head_conv_wgrad: bad args");
   hipStream_t st = (hipStream_t)s;
   const long long P = (long long)images * H * W;
   int ppb = (int)((P + EDGE_WGRAD_BLOCKS - 1) / EDGE_WGRAD_BLOCKS);
   if (ppb < 1) ppb = 1;
   const int nb = cdiv(P, ppb);
-  EDGE_DISPATCH(Cout, hipLaunchKernelGGL(head_wgrad_kernel<EC>, dim3(nb), dim3(256), 0, st, x, g, ws, db, images, Cin, H, W,
+  EDGE_DISPATCH(Cout, hipLaunchKernelGGL((head_wgrad_kernel<EC, TX>), dim3(nb), dim3(256), 0, st, x, g, ws, db, images, Cin, H, W,
                                          ppb));
   SDM_CHECK_LAUNCH("head_conv_wgrad");
   hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(cdiv((long)9 * Cout * Cin, 256)), dim3(256), 0, st, ws, dw, nb, Cin, Cout);
   SDM_CHECK_LAUNCH("head_wgrad_reduce");
   return SDM_OK;
+}
+
+extern "C" int sdm_head_conv_wgrad(const float* x, const float* g, float* dw, float* db, float* ws, int images, int Cin,
+                                   int H, int W, int Cout, sdm_stream_t s) {
+  return head_conv_wgrad_impl<float>(x, g, dw, db, ws, images, Cin, H, W, Cout, s);
+}
+extern "C" int sdm_head_conv_wgrad_bf16(const uint16_t* x, const float* g, float* dw, float* db, float* ws, int images, int Cin,
+                                        int H, int W, int Cout, sdm_stream_t s) {
+  return head_conv_wgrad_impl<bf16_t>((const bf16_t*)x, g, dw, db, ws, images, Cin, H, W, Cout, s);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -611,6 +647,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     if (z) v *= sdm_dsilu(z[r * ldz + c]);
     dz[r * lddz + c] = v;
   }
+}
+
+// host-side launcher of the coefficient pass, shared with the bf16 rows variant (sdm_bf16_train.hip)
+int sdm_launch_gn_bwd_coef(float* ws, int images, int HW, int C, int groups, const float* gamma, const float* beta,
+                           const float* mod, int mod_ns, const float* mean, const float* rstd, float* coef, float* dmod,
+                           float* dgamma, float* dbeta, hipStream_t st) {
+  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(images * groups), dim3(64), 0, st, ws, HW, C, groups, gamma, beta, mod, mod_ns,
+                     mean, rstd, coef, dmod, dgamma, dbeta);
+  SDM_CHECK_LAUNCH("gn_bwd_coef");
+  return SDM_OK;
 }
 
 extern "C" int sdm_gn_adagn_bwd(const float* dout, int64_t lddo, const float* y, int64_t ldy, const float* z, int64_t ldz,

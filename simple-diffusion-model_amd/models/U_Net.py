@@ -50,6 +50,8 @@ class U_Net(nn.Module):
         self.num_layers, self.image_recon = num_layers, image_recon
         # storage type of no-grad forwards; SDM_INFER_DTYPE=bf16 selects the bf16 sampling path (set_inference_dtype)
         self.inference_dtype = torch.bfloat16 if os.environ.get("SDM_INFER_DTYPE", "") == "bf16" else torch.float32
+        # storage type of training forwards/backwards; SDM_TRAIN_DTYPE=bf16 selects the bf16 training path (set_training_dtype)
+        self.training_dtype = torch.bfloat16 if os.environ.get("SDM_TRAIN_DTYPE", "") == "bf16" else torch.float32
         self.in_channel, self.out_channel = in_channel, out_channel
 
         self.cond_emb = ConditionalEmbedding(time_dim, cond_dim) if time_dim is not None else None
@@ -214,8 +216,11 @@ class U_Net(nn.Module):
         st = ops._stream()
         slab = self._edge_slab(dout.device)
 
+        bf = ctx.bf16
+        sfx = "_bf16" if bf else ""
+
         def head_wgrad():
-            ops.lib.call("sdm_head_conv_wgrad", hin.t.data_ptr(), dout.data_ptr(),
+            ops.lib.call("sdm_head_conv_wgrad" + sfx, hin.t.data_ptr(), dout.data_ptr(),
                          head.grad_taps(grads[head.weight]).data_ptr(), grads[head.bias].data_ptr(), slab.data_ptr(), n, hin.c,
                          H, W, self.out_channel, ops._stream())
         if ops.SIDE.enabled:           # edge weight gradients ride the side stream too (they share `slab`: same stream)
@@ -224,7 +229,7 @@ class U_Net(nn.Module):
         else:
             head_wgrad()
         dz = torch.empty_like(hin.t)
-        ops.lib.call("sdm_head_conv_dgrad", dout.data_ptr(), head.taps().data_ptr(), dz.data_ptr(), hin.z.data_ptr(), n,
+        ops.lib.call("sdm_head_conv_dgrad" + sfx, dout.data_ptr(), head.taps().data_ptr(), dz.data_ptr(), hin.z.data_ptr(), n,
                      hin.c, H, W, self.out_channel, st)
         dz = self.out_layers[0].backward(ctx, dz, grads)                 # -> dz of the last up-sampler
         user_hook = getattr(self, "_block_done_hook", None)
@@ -251,7 +256,7 @@ class U_Net(nn.Module):
         stem = self.in_layer[0].conv_layer.conv
         x = ctx.rec["x"]
         def stem_wgrad():
-            ops.lib.call("sdm_stem_conv_wgrad", x.data_ptr(), dz.data_ptr(), stem.grad_taps(grads[stem.weight]).data_ptr(),
+            ops.lib.call("sdm_stem_conv_wgrad" + sfx, x.data_ptr(), dz.data_ptr(), stem.grad_taps(grads[stem.weight]).data_ptr(),
                          grads[stem.bias].data_ptr(), slab.data_ptr(), x.shape[0], x.shape[1], x.shape[2], x.shape[3],
                          stem.cout, ops._stream())
         if ops.SIDE.enabled:
@@ -267,11 +272,21 @@ class U_Net(nn.Module):
             hook("cond_emb")
         ops.SIDE.join()
 
+    def set_training_dtype(self, dtype):
+        """Storage type of activations, activation gradients and the contraction weight copies in TRAINING forwards /
+        backwards: torch.float32 (default, the parity path) or torch.bfloat16 (fp32 master weights, fp32 weight gradients
+        and optimizer; every sum fp32; gradients within rel-L2 ~1e-2 of fp32).  The counterpart of the reference's fp16
+        autocast (train_diffusion.py:333); additive API."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("training dtype must be torch.float32 or torch.bfloat16")
+        self.training_dtype = dtype
+        return self
+
     def loss_and_grads(self, x, t, cond, target, grads=None):
         """One training forward+backward of mean-squared error against ``target`` without going through autograd:
         returns (loss tensor [1], {param: grad}).  Used by the fused trainer and the benchmark."""
         self._check_input(x)
-        ctx = RunCtx(True)
+        ctx = RunCtx(True, bf16=self.training_dtype == torch.bfloat16)
         out = self._run(ctx, x, t, cond)
         loss, dout = ops.mse(out, target.contiguous(), want_grad=True)
         if grads is None:
@@ -285,7 +300,7 @@ class _UNetFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(fctx, net, x, t, cond, *params):
-        ctx = RunCtx(True)
+        ctx = RunCtx(True, bf16=net.training_dtype == torch.bfloat16)
         out = net._run(ctx, x.detach(), t, cond)
         fctx.net, fctx.run, fctx.out, fctx.params = net, ctx, out, params
         return out

@@ -42,7 +42,8 @@ class RunCtx:
 
     def __init__(self, train=False, bf16=False):
         self.train = train
-        self.bf16 = bf16 and not train     # bf16 storage path: forward (sampling) only
+        self.bf16 = bf16                   # bf16 storage: sampling forwards, and the bf16 training path (fp32 master
+                                           # weights / weight gradients / optimizer, everything summed in fp32)
         self.rec = {}
         self.emb = None
         self.demb = None
@@ -54,15 +55,18 @@ class RunCtx:
 MATERIALIZE_TRAIN = [os.environ.get("SDM_TRAIN_MATERIALIZE", "1") != "0"]
 
 
-def bf16_weight(mod, key, src_fn):
-    """bf16 copy of a contraction weight for the sampling path, rebuilt when the fp32 master changed (in-place torch
-    updates bump ``_version``; the fused optimizer, which writes through raw pointers, bumps ops.WEIGHT_EPOCH)."""
+def bf16_weight(mod, key, src_fn, transposed=False):
+    """bf16 copy of a contraction weight, refreshed IN PLACE when the fp32 master changed (in-place torch updates bump
+    ``_version``; the fused optimizer, which writes through raw pointers, bumps ops.WEIGHT_EPOCH) -- the copy keeps its
+    address, so captured graphs stay valid.  ``transposed``: [T, R, C] -> [T, C, R] (what a bf16 data gradient reads)."""
     w = mod._parameters["weight"]
     tag = (w.data_ptr(), w._version, ops.WEIGHT_EPOCH[0])
     cache = mod.__dict__.setdefault("_bf16_cache", {})
     hit = cache.get(key)
     if hit is None or hit[0] != tag:
-        cache[key] = hit = (tag, ops.to_bf16(src_fn()))
+        keep = hit[1] if (hit is not None and hit[0][0] == tag[0]) else None
+        fn = ops.to_bf16_t if transposed else ops.to_bf16
+        cache[key] = hit = (tag, fn(src_fn(), out=keep))
     return hit[1]
 
 
@@ -100,6 +104,13 @@ class TapLinear(nn.Module):
 
     def weight_for(self, ctx):
         return bf16_weight(self, "w", lambda: self.weight) if ctx.bf16 else self.weight
+
+    def weight_t_for(self, ctx):
+        """What the data gradient contracts against: the fp32 weight itself (read K-major), or -- bf16 -- the transposed
+        copy [in, out]."""
+        if not ctx.bf16:
+            return self.weight
+        return bf16_weight(self, "wt", lambda: self.weight.detach()[None], transposed=True)[0]
 
 
 class TapNorm(nn.Module):
@@ -151,6 +162,10 @@ class TapConv(nn.Module):
     def taps_for(self, ctx):
         return bf16_weight(self, "taps", self.taps) if ctx.bf16 else self.taps()
 
+    def taps_t_for(self, ctx):
+        """Weights for the data gradient: fp32 taps (read K-major) or the transposed bf16 copy [taps, c_in, c_out]."""
+        return bf16_weight(self, "taps_t", self.taps, transposed=True) if ctx.bf16 else self.taps()
+
     def grad_taps(self, g):
         v = self._tapview(g)
         if not v.is_contiguous():
@@ -158,11 +173,12 @@ class TapConv(nn.Module):
         k = v.shape[0]
         return v.view(k * k, self.cout, self.cin)
 
-    def backward(self, x, y_hw, dz, grads, res=None, res2=None, need_dx=True):
+    def backward(self, x, y_hw, dz, grads, res=None, res2=None, need_dx=True, ctx=None):
         """dz: gradient w.r.t. this conv's pre-activation [n*ho*wo, cout] (any pitch).  Writes weight/bias
         gradients; returns the gradient w.r.t. the input rows -- already multiplied by silu'(x.z) when the
-        input is itself an activation output (then it is that producer's dz)."""
+        input is itself an activation output (then it is that producer's dz).  ``ctx`` selects the bf16 path."""
         self.taps()
+        wt_d = self.taps_t_for(ctx) if ctx is not None else self.taps()
         if ops.SIDE.enabled:            # weight gradient on the side stream, concurrent with the data gradient below
             with ops.SIDE.fork(dz, x.t, x.t2, x.scale, x.shift):
                 ops.conv_wgrad(dz, y_hw, x, self.kind, self.grad_taps(grads[self.weight]), dbias=grads[self.bias])
@@ -171,7 +187,7 @@ class TapConv(nn.Module):
         if not need_dx:
             return None
         ncols = x.c1 if x.t2 is not None else 0
-        return ops.conv_dgrad(dz, y_hw, self.taps(), self.kind, (x.h, x.w), x.n, res=res, res2=res2,
+        return ops.conv_dgrad(dz, y_hw, wt_d, self.kind, (x.h, x.w), x.n, res=res, res2=res2,
                               dact_z=x.z, dact_ncols=ncols)
 
 
@@ -185,9 +201,10 @@ class AdaGN(nn.Module):
     def modulation(self, emb):
         return ops.linear_small(emb, self.y_scale.weight, self.y_scale.bias)
 
-    def fold(self, y, mod):
+    def fold(self, y, mod, want_stats=True):
         """-> (scale, shift, mean, rstd) with scale*y+shift == s*GN(y)+s."""
-        return ops.gn_affine(y, self.group_norm.weight, self.group_norm.bias, mod, self.group_norm.groups)
+        return ops.gn_affine(y, self.group_norm.weight, self.group_norm.bias, mod, self.group_norm.groups,
+                             want_stats=want_stats)
 
     def backward(self, ctx, dout, y, mod, mean, rstd, grads):
         """dout: gradient w.r.t. the modulated tensor.  Returns dz of the producing conv."""
@@ -309,7 +326,11 @@ class AttentionBlock(nn.Module):
         S = x.h * x.w
         qkv = ops.linear_rows(x.t, self.projection.weight_for(ctx), self.projection.bias)
         if ctx.bf16:
-            res = ops.attention_core_fwd_bf16(qkv, x.n, S, self.heads, self.d_k)
+            if ctx.train:
+                res, P = ops.attention_core_fwd_bf16(qkv, x.n, S, self.heads, self.d_k, keep_p=True)
+                ctx.rec[self] = (x, qkv, P, res)
+            else:
+                res = ops.attention_core_fwd_bf16(qkv, x.n, S, self.heads, self.d_k)
             out = ops.linear_rows(res, self.output.weight_for(ctx), self.output.bias, res=x.t)
             return Act(out, x.n, x.h, x.w)
         res, P = ops.attention_core_fwd(qkv, x.n, S, self.heads, self.d_k)
@@ -327,14 +348,15 @@ class AttentionBlock(nn.Module):
                 ops.linear_rows_wgrad(dO, res, grads[self.output.weight], dbias=grads[self.output.bias])
         else:
             ops.linear_rows_wgrad(dO, res, grads[self.output.weight], dbias=grads[self.output.bias])
-        dres = ops.linear_rows_dgrad(dO, self.output.weight)
-        dqkv = ops.attention_core_bwd(dres, qkv, P, x.n, S, self.heads, self.d_k)
+        dres = ops.linear_rows_dgrad(dO, self.output.weight_t_for(ctx))
+        core_bwd = ops.attention_core_bwd_bf16 if ctx.bf16 else ops.attention_core_bwd
+        dqkv = core_bwd(dres, qkv, P, x.n, S, self.heads, self.d_k)
         if ops.SIDE.enabled:
             with ops.SIDE.fork(dqkv, x.t):
                 ops.linear_rows_wgrad(dqkv, x.t, grads[self.projection.weight], dbias=grads[self.projection.bias])
         else:
             ops.linear_rows_wgrad(dqkv, x.t, grads[self.projection.weight], dbias=grads[self.projection.bias])
-        return ops.linear_rows_dgrad(dqkv, self.projection.weight, res=dO)
+        return ops.linear_rows_dgrad(dqkv, self.projection.weight_t_for(ctx), res=dO)
 
     def forward(self, x, t=None):
         return to_nchw(self.run(RunCtx(False), to_rows(x)))
@@ -368,7 +390,7 @@ class _ResampleBlock(nn.Module):
 
     def backward(self, ctx, dz, grads, res=None, res2=None):
         x, y = ctx.rec[self]
-        return self.conv_layer.conv.backward(x, (y.h, y.w), dz, grads, res=res, res2=res2)
+        return self.conv_layer.conv.backward(x, (y.h, y.w), dz, grads, res=res, res2=res2, ctx=ctx)
 
     def forward(self, x, emb=None):
         return to_nchw(self.run(RunCtx(False), to_rows(x)))
@@ -402,7 +424,7 @@ class UNet_ConvBlock(nn.Module):
                 ctx.rec[self] = (x, y, None, None, None)
             return y, None
         mod = ctx.mods[self.adagn] if ctx.mods is not None else self.adagn.modulation(emb)
-        scale, shift, mean, rstd = self.adagn.fold(y, mod)
+        scale, shift, mean, rstd = self.adagn.fold(y, mod, want_stats=ctx.train)
         if ctx.train:
             ctx.rec[self] = (x, y, mod, mean, rstd)
         return y, (scale, shift)
@@ -412,7 +434,7 @@ class UNet_ConvBlock(nn.Module):
         pre-activation gradient (dz)."""
         x, y, mod, mean, rstd = ctx.rec[self]
         dz = g if mod is None else self.adagn.backward(ctx, g, y, mod, mean, rstd, grads)
-        return self.conv_layer.conv.backward(x, (y.h, y.w), dz, grads, res=res, res2=res2)
+        return self.conv_layer.conv.backward(x, (y.h, y.w), dz, grads, res=res, res2=res2, ctx=ctx)
 
     def forward(self, x, emb=None):
         y, aff = self.run(RunCtx(False), to_rows(x), None if emb is None else emb.contiguous())

@@ -124,12 +124,23 @@ _PROTOS = {
     "sdm_igemm_bf16": (_i, [C.POINTER(IgemmDesc), _i, fp]),
     "sdm_igemm_bf16_workspace_bytes": (_sz, [C.POINTER(IgemmDesc)]),
     "sdm_cast_bf16": (_i, [fp, fp, _sz, fp]),
-    "sdm_stem_conv_bf16": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
+    "sdm_stem_conv_bf16": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
     "sdm_head_conv_bf16": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
-    "sdm_gn_affine_bf16": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, fp, fp]),
+    "sdm_gn_affine_bf16": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, fp, fp, fp, fp]),
     "sdm_affine_residual_bf16": (_i, [fp, _i64, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, _i, _i, _i, fp]),
     "sdm_col_softmax_bf16": (_i, [fp, fp, _i, _i, _i64, _i64, fp]),
     "sdm_transpose_bf16": (_i, [fp, _i64, _i64, _i64, _i, fp, _i64, _i64, _i, _i, _i, fp]),
+    # bf16 training path
+    "sdm_wgrad_bf16": (_i, [C.POINTER(WgradDesc), fp]),
+    "sdm_cast_bf16_t": (_i, [fp, fp, _i, _i, _i, fp]),
+    "sdm_gn_adagn_bwd_bf16": (_i, [fp, _i64, fp, _i64, fp, _i64, _i, _i, _i, _i, fp, fp, fp, _i, fp, fp, fp, _i64,
+                                   fp, fp, fp, fp, fp, fp]),
+    "sdm_col_softmax_bwd_bf16": (_i, [fp, _i64, fp, _i64, fp, _i64, _i, _i, _f, fp]),
+    "sdm_silu_bwd_bf16": (_i, [fp, fp, fp, _sz, fp]),
+    "sdm_colsum_bf16": (_i, [fp, _i64, _i, _i, fp, fp]),
+    "sdm_stem_conv_wgrad_bf16": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "sdm_head_conv_dgrad_bf16": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "sdm_head_conv_wgrad_bf16": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
 }
 EXPORTS = tuple(_PROTOS)
 

@@ -212,13 +212,27 @@ def _launch_igemm(d, device, bf16=False, out_f32=False):
         lib.call("sdm_igemm", C.byref(d), _stream())
 
 
-def to_bf16(t):
-    """Round-to-nearest-even bf16 copy of an fp32 tensor, keeping its memory layout (weights, once per checkpoint)."""
+def to_bf16(t, out=None):
+    """Round-to-nearest-even bf16 copy of an fp32 tensor, keeping its memory layout (weights).  ``out``: a copy made
+    earlier, refreshed in place (its address stays valid for captured graphs)."""
     src = t.detach()
-    flat = torch.empty(src.numel(), dtype=BF16, device=src.device)
     dense = src.as_strided((src.numel(),), (1,)) if not src.is_contiguous() else src.reshape(-1)
-    lib.call("sdm_cast_bf16", _p(dense), _p(flat), src.numel(), _stream())
-    return flat.as_strided(src.shape, src.stride())
+    if out is None:
+        flat = torch.empty(src.numel(), dtype=BF16, device=src.device)
+        out = flat.as_strided(src.shape, src.stride())
+    lib.call("sdm_cast_bf16", _p(dense), _p(out), src.numel(), _stream())
+    return out
+
+
+def to_bf16_t(w3, out=None):
+    """Transposed bf16 copy of a contiguous fp32 [T, R, C] tensor -> [T, C, R] (the weight layout a bf16 DATA gradient
+    contracts against: tap-major conv weights [tap][c_out][c_in] -> [tap][c_in][c_out]; Linear [O][K] -> [1][K][O])."""
+    T, R, C_ = w3.shape
+    assert w3.is_contiguous()
+    if out is None:
+        out = torch.empty((T, C_, R), dtype=BF16, device=w3.device)
+    lib.call("sdm_cast_bf16_t", _p(w3), _p(out), T, R, C_, _stream())
+    return out
 
 
 def _base_desc(M, N, K):
@@ -245,8 +259,8 @@ def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False):
     assert cin == x.c, (cin, x.c)
     ho, wo = conv_out_hw(x.h, x.w, kind)
     bf = wt.dtype == BF16
-    if bf and (save_z or x.scale is not None or x.t.dtype != BF16):
-        raise lib.SdmError("bf16 conv: forward-only path on plain bf16 rows")
+    if bf and (x.scale is not None or x.t.dtype != BF16):
+        raise lib.SdmError("bf16 conv: needs plain bf16 rows (materialise a pending affine first)")
     out = torch.empty((x.n * ho * wo, cout), dtype=wt.dtype, device=wt.device)
     z = torch.empty_like(out) if save_z else None
     if kind == "ct4":
@@ -273,12 +287,18 @@ def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False):
 
 
 def conv_dgrad(g, g_hw, wt, kind, x_hw, n, res=None, res2=None, dact_z=None, dact_ncols=0, out=None):
-    """Data gradient of conv_fwd.  g: [n*ho*wo, c_out] (pitch g.stride(0)); returns dx [n*h*w, c_in]."""
-    T, cout, cin = wt.shape
+    """Data gradient of conv_fwd.  g: [n*ho*wo, c_out] (pitch g.stride(0)); returns dx [n*h*w, c_in].
+    fp32: ``wt`` is the forward weight [taps, c_out, c_in], read K-major.  bf16: ``wt`` is the TRANSPOSED copy
+    [taps, c_in, c_out] (to_bf16_t), so that both operands stay reduction-contiguous; g / res / res2 / dact_z bf16."""
+    bf = wt.dtype == BF16
+    if bf:
+        T, cin, cout = wt.shape
+    else:
+        T, cout, cin = wt.shape
     ho, wo = g_hw
     h, w = x_hw
     if out is None:
-        out = torch.empty((n * h * w, cin), dtype=torch.float32, device=wt.device)
+        out = torch.empty((n * h * w, cin), dtype=wt.dtype, device=wt.device)
     ga = Act(g, n, ho, wo)
     if kind == "c3s1":
         d = _base_desc(n * h * w, cin, cout)
@@ -300,7 +320,10 @@ def conv_dgrad(g, g_hw, wt, kind, x_hw, n, res=None, res2=None, dact_z=None, dac
     else:
         raise ValueError(kind)
     fill_rows(d.a, ga)
-    d.b, d.ldb, d.b_tap_stride, d.b_kmajor = _p(wt), cin, cout * cin, 1
+    if bf:
+        d.b, d.ldb, d.b_tap_stride, d.b_kmajor = _p(wt), cout, cout * cin, 0
+    else:
+        d.b, d.ldb, d.b_tap_stride, d.b_kmajor = _p(wt), cin, cout * cin, 1
     d.Ho, d.Wo = h, w
     d.out, d.ldo = _p(out), out.stride(0)
     d.act = ACT_NONE
@@ -310,7 +333,7 @@ def conv_dgrad(g, g_hw, wt, kind, x_hw, n, res=None, res2=None, dact_z=None, dac
         d.res2, d.ldres2 = _p(res2), res2.stride(0)
     if dact_z is not None:
         d.dact_z, d.ldz, d.dact_ncols = _p(dact_z), dact_z.stride(0), dact_ncols
-    _launch_igemm(d, wt.device)
+    _launch_igemm(d, wt.device, bf16=bf)
     return out
 
 
@@ -340,7 +363,7 @@ def conv_wgrad(g, g_hw, x, kind, dwt, accumulate=2, dbias=None):
     d.alpha, d.accumulate = 1.0, int(accumulate)
     if dbias is not None and kind != "ct4":
         d.dbias = _p(dbias)
-    lib.call("sdm_wgrad", C.byref(d), _stream())
+    lib.call("sdm_wgrad_bf16" if g.dtype == BF16 else "sdm_wgrad", C.byref(d), _stream())
     if dbias is not None and kind == "ct4":        # gathered gradient rows: separate column sum
         colsum(g, dbias)
 
@@ -372,26 +395,27 @@ def linear_rows(x, W, b, act=ACT_NONE, res=None, save_z=False, out=None, ldres=N
 
 
 def linear_rows_dgrad(g, W, res=None, out=None):
-    """dx [rows, K] = g [rows, O] @ W[O, K] (+ res)."""
+    """dx [rows, K] = g [rows, O] @ W[O, K] (+ res).  bf16: ``W`` is the transposed copy [K, O] (to_bf16_t)."""
     rows, O = g.shape
-    K = W.shape[1]
+    bf = W.dtype == BF16
+    K = W.shape[0] if bf else W.shape[1]
     if out is None:
-        out = torch.empty((rows, K), dtype=torch.float32, device=g.device)
+        out = torch.empty((rows, K), dtype=W.dtype, device=g.device)
     d = _base_desc(rows, K, O)
     d.Ht, d.Wt = rows, 1
     plain_rows(d.a, g)
-    d.b, d.ldb, d.b_tap_stride, d.b_kmajor = _p(W), W.stride(0), 0, 1
+    d.b, d.ldb, d.b_tap_stride, d.b_kmajor = _p(W), W.stride(0), 0, 0 if bf else 1
     d.ntaps[0] = 1
     d.Ho, d.Wo = rows, 1
     d.out, d.ldo = _p(out), out.stride(0)
     if res is not None:
         d.res, d.ldres = _p(res), res.stride(0)
-    _launch_igemm(d, g.device)
+    _launch_igemm(d, g.device, bf16=bf)
     return out
 
 
 def linear_rows_wgrad(g, x, dW, accumulate=2, dbias=None):
-    """dW[O, K] (+)= g[rows, O]^T @ x[rows, K]  (+ dbias[O] += column sums of g)."""
+    """dW[O, K] (+)= g[rows, O]^T @ x[rows, K]  (+ dbias[O] += column sums of g); g / x fp32 or both bf16, dW fp32."""
     rows, O = g.shape
     K = x.shape[1]
     d = WgradDesc()
@@ -404,7 +428,7 @@ def linear_rows_wgrad(g, x, dW, accumulate=2, dbias=None):
     d.dw, d.ldw, d.w_tap_stride = _p(dW), dW.stride(0), 0
     d.alpha, d.accumulate = 1.0, int(accumulate)
     d.dbias = _p(dbias)
-    lib.call("sdm_wgrad", C.byref(d), _stream())
+    lib.call("sdm_wgrad_bf16" if g.dtype == BF16 else "sdm_wgrad", C.byref(d), _stream())
 
 
 def _pad4(s):
@@ -451,9 +475,9 @@ def _pad8(s):
     return (s + 7) // 8 * 8
 
 
-def attention_core_fwd_bf16(qkv, n, S, heads, dk):
-    """bf16 form of attention_core_fwd (forward only): scores are produced in fp32, the column softmax writes bf16
-    probabilities, V is transposed once so that P.V contracts two token-contiguous operands.  Returns res bf16."""
+def attention_core_fwd_bf16(qkv, n, S, heads, dk, keep_p=False):
+    """bf16 form of attention_core_fwd: scores are produced in fp32, the column softmax writes bf16 probabilities, V is
+    transposed once so that P.V contracts two token-contiguous operands.  Returns res bf16 (and P with keep_p)."""
     dev = qkv.device
     Sp = _pad8(S)
     ld = qkv.stride(0)
@@ -472,6 +496,7 @@ def attention_core_fwd_bf16(qkv, n, S, heads, dk):
     _launch_igemm(d, dev, bf16=True, out_f32=True)
     P = torch.empty((n * heads, S, Sp), dtype=BF16, device=dev)
     lib.call("sdm_col_softmax_bf16", _p(scores), _p(P), n * heads, S, Sp, Sp, _stream())
+    del scores
     Vt = torch.empty((n * heads, dk, Sp), dtype=BF16, device=dev)
     lib.call("sdm_transpose_bf16", qkv.data_ptr() + 4 * dk, ld, S * ld, 3 * dk, heads, _p(Vt), Sp, dk * Sp, n * heads, S, dk,
              _stream())
@@ -488,7 +513,77 @@ def attention_core_fwd_bf16(qkv, n, S, heads, dk):
     d.Ho, d.Wo = S, 1
     d.out, d.ldo, d.o_bs0, d.o_bs1 = _p(res), heads * dk, S * heads * dk, dk
     _launch_igemm(d, dev, bf16=True)
-    return res
+    return (res, P) if keep_p else res
+
+
+def attention_core_bwd_bf16(dres, qkv, P, n, S, heads, dk):
+    """bf16 backward of the attention core: returns dqkv bf16 [n*S, heads*3*dk] given dres bf16 [n*S, heads*dk] and the
+    saved qkv / P (bf16).  dV and dK are token-reduction (weight-gradient shaped) products -> sdm_wgrad_bf16 into an fp32
+    buffer; dP and dQ are row products -> sdm_igemm_bf16 with fp32 output; one cast at the end."""
+    dev = qkv.device
+    Sp = P.shape[2]
+    ld = qkv.stride(0)
+    dq32 = torch.zeros((n * S, heads * 3 * dk), dtype=torch.float32, device=dev)     # k / v slots take split-K atomics
+    ldq = dq32.stride(0)
+    st = _stream()
+    B = n * heads
+
+    def token_product(g3, x2d, x_off_elems, x_bs, slot):
+        """dq32[slot][j][dd] = sum_i g3[b][i][j] * x[b][i][dd]"""
+        w = WgradDesc()
+        w.M, w.N, w.batch, w.bdiv = S, dk, B, heads
+        w.images, w.Hk, w.Wk = 1, S, 1
+        plain_rows(w.g, g3[0], rows=S)
+        w.g.ld0 = Sp
+        w.g_bs0, w.g_bs1 = heads * S * Sp, S * Sp
+        plain_rows(w.x, x2d, rows=S)
+        w.x.p0 = x2d.data_ptr() + 2 * x_off_elems
+        w.x_bs0, w.x_bs1 = S * x2d.stride(0), x_bs
+        w.g_stride = w.x_stride = 1
+        w.ntaps = 1
+        w.dw, w.ldw = dq32.data_ptr() + 4 * slot * dk, ldq
+        w.w_bs0, w.w_bs1 = S * ldq, 3 * dk
+        w.alpha, w.accumulate = 1.0, 2
+        lib.call("sdm_wgrad_bf16", C.byref(w), st)
+
+    # dV[j][dd] = sum_i P[i][j] dres[i][dd]
+    token_product(P, dres, 0, dk, 2)
+    # dP[i][j] = sum_dd dres[i][dd] v[j][dd]   (fp32, ahead of the softmax backward)
+    dP = torch.empty((B, S, Sp), dtype=torch.float32, device=dev)
+    d = _base_desc(S, S, dk)
+    d.batch, d.bdiv = B, heads
+    d.Ht, d.Wt = S, 1
+    plain_rows(d.a, dres, rows=S)
+    d.a_bs0, d.a_bs1 = S * dres.stride(0), dk
+    d.b, d.ldb, d.b_kmajor = qkv.data_ptr() + 4 * dk, ld, 0
+    d.b_bs0, d.b_bs1 = S * ld, 3 * dk
+    d.ntaps[0] = 1
+    d.Ho, d.Wo = S, 1
+    d.out, d.ldo, d.o_bs0, d.o_bs1 = _p(dP), Sp, heads * S * Sp, S * Sp
+    _launch_igemm(d, dev, bf16=True, out_f32=True)
+    dS = torch.empty((B, S, Sp), dtype=BF16, device=dev)
+    lib.call("sdm_col_softmax_bwd_bf16", _p(P), Sp, _p(dP), Sp, _p(dS), Sp, B, S, float(dk) ** -0.5, st)
+    del dP
+    # dQ[i][dd] = sum_j dS[i][j] k[j][dd]: K transposed once so that both operands are contiguous along j
+    Kt = torch.empty((B, dk, Sp), dtype=BF16, device=dev)
+    lib.call("sdm_transpose_bf16", qkv.data_ptr() + 2 * dk, ld, S * ld, 3 * dk, heads, _p(Kt), Sp, dk * Sp, B, S, dk, st)
+    d = _base_desc(S, dk, Sp)
+    d.batch, d.bdiv = B, heads
+    d.Ht, d.Wt = S, 1
+    plain_rows(d.a, dS[0], rows=S)
+    d.a.ld0 = Sp
+    d.a_bs0, d.a_bs1 = heads * S * Sp, S * Sp
+    d.b, d.ldb, d.b_kmajor = _p(Kt), Sp, 0
+    d.b_bs0, d.b_bs1 = heads * dk * Sp, dk * Sp
+    d.ntaps[0] = 1
+    d.Ho, d.Wo = S, 1
+    d.out, d.ldo, d.o_bs0, d.o_bs1 = _p(dq32), ldq, S * ldq, 3 * dk
+    _launch_igemm(d, dev, bf16=True, out_f32=True)
+    # dK[j][dd] = sum_i dS[i][j] q[i][dd]
+    token_product(dS, qkv, 0, 3 * dk, 1)
+    dqkv = torch.empty((n * S, heads * 3 * dk), dtype=BF16, device=dev)
+    lib.call("sdm_cast_bf16", _p(dq32), _p(dqkv), dq32.numel(), st)
+    return dqkv
 
 
 def attention_core_bwd(dres, qkv, P, n, S, heads, dk):
@@ -566,8 +661,9 @@ def stem_conv(x_nchw, wt, bias, act=ACT_SILU, save_z=False, out_dtype=torch.floa
     cout = wt.shape[1]
     if out_dtype == BF16:
         out = torch.empty((n * h * w, cout), dtype=BF16, device=wt.device)
-        lib.call("sdm_stem_conv_bf16", _p(x_nchw), _p(wt), _p(bias), _p(out), n, cin, h, w, cout, act, _stream())
-        return Act(out, n, h, w)
+        z = torch.empty_like(out) if save_z else None
+        lib.call("sdm_stem_conv_bf16", _p(x_nchw), _p(wt), _p(bias), _p(out), _p(z), n, cin, h, w, cout, act, _stream())
+        return Act(out, n, h, w, z=z)
     out = torch.empty((n * h * w, cout), dtype=torch.float32, device=wt.device)
     z = torch.empty_like(out) if save_z else None
     lib.call("sdm_stem_conv", _p(x_nchw), _p(wt), _p(bias), _p(out), _p(z), n, cin, h, w, cout, act, _stream())
@@ -584,17 +680,20 @@ def head_conv(x, wt, bias, act=ACT_NONE):
     return out
 
 
-def gn_affine(y, gamma, beta, mod, groups=32, eps=1e-5):
-    """y: Act (plain).  Returns (scale, shift, mean, rstd); scale/shift are [n, C]."""
+def gn_affine(y, gamma, beta, mod, groups=32, eps=1e-5, want_stats=True):
+    """y: Act (plain).  Returns (scale, shift, mean, rstd); scale/shift are [n, C] fp32 (on bf16 rows mean / rstd are
+    None unless ``want_stats``: only the training path's backward needs them)."""
     C_ = y.c
     dev = y.t.device
     scale = torch.empty((y.n, C_), dtype=torch.float32, device=dev)
     shift = torch.empty_like(scale)
     mns = 0 if (mod is None or mod.shape[0] == 1) else mod.stride(0)
     if y.t.dtype == BF16:
+        mean = torch.empty((y.n, groups), dtype=torch.float32, device=dev) if want_stats else None
+        rstd = torch.empty_like(mean) if want_stats else None
         lib.call("sdm_gn_affine_bf16", _p(y.t), y.t.stride(0), y.n, y.h * y.w, C_, groups, eps, _p(gamma), _p(beta), _p(mod),
-                 mns, _p(scale), _p(shift), _stream())
-        return scale, shift, None, None
+                 mns, _p(scale), _p(shift), _p(mean), _p(rstd), _stream())
+        return scale, shift, mean, rstd
     mean = torch.empty((y.n, groups), dtype=torch.float32, device=dev)
     rstd = torch.empty_like(mean)
     mns = 0 if (mod is None or mod.shape[0] == 1) else mod.stride(0)
@@ -627,13 +726,13 @@ def gn_adagn_bwd(dout, y, z, n, hw, gamma, beta, mod, mean, rstd, dgamma, dbeta,
     """Returns (dz [rows, C], dmod [n, C] or None).  ``dmod`` may be a preallocated contiguous [n, C] view."""
     C_ = y.shape[1]
     dev = y.device
-    dz = torch.empty((n * hw, C_), dtype=torch.float32, device=dev)
+    dz = torch.empty((n * hw, C_), dtype=y.dtype, device=dev)
     if dmod is None and mod is not None:
         dmod = torch.empty((n, C_), dtype=torch.float32, device=dev)
     ws = GNWS.get(n * C_ * 2 * 4, dev)         # persistent, zero-filled; the kernels leave it zero
     coef = torch.empty((n * 3 * C_,), dtype=torch.float32, device=dev)
     mns = 0 if (mod is None or mod.shape[0] == 1) else mod.stride(0)
-    lib.call("sdm_gn_adagn_bwd", _p(dout), dout.stride(0), _p(y), y.stride(0), _p(z), z.stride(0) if z is not None else 0,
+    lib.call("sdm_gn_adagn_bwd_bf16" if y.dtype == BF16 else "sdm_gn_adagn_bwd", _p(dout), dout.stride(0), _p(y), y.stride(0), _p(z), z.stride(0) if z is not None else 0,
              n, hw, C_, groups, _p(gamma), _p(beta), _p(mod), mns, _p(mean), _p(rstd), _p(dz), dz.stride(0), _p(dmod),
              _p(dgamma), _p(dbeta), _p(ws), _p(coef), _stream())
     return dz, dmod
@@ -674,6 +773,11 @@ def linear_small_bwd(dy, x, W, dx=None, dx_accumulate=False, dW=None, db=None):
 
 
 def colsum(x, out, accumulate=True):
+    if x.dtype == BF16:
+        if not accumulate:
+            raise lib.SdmError("colsum on bf16 rows accumulates (hand in a zero-filled buffer)")
+        lib.call("sdm_colsum_bf16", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), _stream())
+        return
     lib.call("sdm_colsum", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), int(accumulate), _stream())
 
 
@@ -687,7 +791,7 @@ def silu(x):
 def silu_bwd(dy, z, dx=None):
     if dx is None:
         dx = torch.empty_like(dy)
-    lib.call("sdm_silu_bwd", _p(dy), _p(z), _p(dx), dy.numel(), _stream())
+    lib.call("sdm_silu_bwd_bf16" if dy.dtype == BF16 else "sdm_silu_bwd", _p(dy), _p(z), _p(dx), dy.numel(), _stream())
     return dx
 
 

@@ -87,10 +87,14 @@ class FusedAdam:
 
 class DiffusionTrainer:
     def __init__(self, net, schedule, lr=2e-5, betas=(0.5, 0.999), min_noise_step=1, max_actual_noise_step=1000,
-                 bucket_mb=64, process_group=None, seed=None, use_graph=None, sr=None):
+                 bucket_mb=64, process_group=None, seed=None, use_graph=None, sr=None, train_dtype=None):
         """``sr=(lr_dim, sr_dim, cond_t)`` switches to the super-resolution objective of train_SR_diffusion.py:318-374:
-        the net sees cat(q(x0, t), q(lowres(x0), cond_t)) and regresses x0 - lowres(x0)."""
+        the net sees cat(q(x0, t), q(lowres(x0), cond_t)) and regresses x0 - lowres(x0).
+        ``train_dtype=torch.bfloat16`` runs forward/backward in bf16 storage (U_Net.set_training_dtype); weights,
+        gradients and Adam stay fp32."""
         self.sr = sr
+        if train_dtype is not None:
+            net.set_training_dtype(train_dtype)
         self.net, self.schedule = net, schedule
         self.min_t, self.max_t = min_noise_step, max_actual_noise_step
         self.pg = process_group

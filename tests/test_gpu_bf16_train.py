@@ -1,0 +1,287 @@
+"""bf16 TRAINING path (BASELINE configs 4-5): fp32 master weights / weight gradients / optimizer, bf16 activations,
+activation gradients and contraction weight copies, every sum fp32.
+
+The reference has no bf16 mode (its GPU path is fp16 autocast, train_diffusion.py:333,358-364), so the rounding itself is
+"parity unpinned".  Two kinds of checks:
+  * every new kernel against a torch fp32 computation on the SAME bf16-rounded operands (what is left is summation order
+    and, where the kernel writes bf16, one output rounding: rel-L2 <= 4e-3, fp32 outputs <= 1e-4);
+  * whole networks against the reference's fp32 goldens / the fp32 oracle: per-gradient-tensor rel-L2 <= 2e-2 (VERDICT r1
+    item 2), loss within 1e-2 relative.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+BF = torch.bfloat16
+
+
+def rel(a, b):
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def r16(x):
+    """bf16-rounded fp32 copy (round to nearest even, like the kernels' casts)."""
+    return x.to(BF).float()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from models import custom_layers
+    return custom_layers
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import unet_oracle
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    return unet_oracle
+
+
+def rows16(x):      # NCHW cpu tensor -> bf16 NHWC rows on device
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * h * w, c).contiguous().cuda().to(BF)
+
+
+def unrows(t, n, h, w):
+    return t.float().reshape(n, h, w, -1).permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def torch_conv(x, w, b, kind):
+    if kind == "c3s1":
+        return F.conv2d(x, w, b, padding=1)
+    if kind == "c3s2":
+        return F.conv2d(x, w, b, stride=2, padding=1)
+    return F.conv_transpose2d(x, w, b, stride=2, padding=1)
+
+
+CONV_CASES = [
+    # kind, n, cin, cout, h, w
+    ("c3s1", 2, 32, 64, 6, 10),         # 64x64 weight-gradient tiles
+    ("c3s1", 1, 128, 128, 16, 16),      # 128x128 tiles, split over pixels
+    ("c3s1", 3, 40, 24, 5, 7),          # ragged channels (multiples of 8 only), odd image
+    ("c3s1", 1, 256, 256, 4, 4),        # 16 pixels: a single, mostly empty K-step
+    ("c3s1", 4, 64, 192, 32, 32),
+    ("c3s2", 2, 32, 64, 8, 12),
+    ("c3s2", 1, 64, 64, 7, 9),
+    ("ct4", 2, 64, 32, 3, 5),
+    ("ct4", 1, 128, 128, 8, 8),
+]
+
+
+@pytest.mark.parametrize("kind,n,cin,cout,h,w", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad_bf16(dev, L, kind, n, cin, cout, h, w):
+    """Forward with the pre-activation copy, data gradient against the transposed weight copy (times silu' of the
+    producer), weight + bias gradient with transposing LDS reads -- vs torch fp32 on the same bf16-rounded operands."""
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(abs(hash((kind, n, cin, cout, h, w))) % 2**31)
+    conv = L.TapConv(cin, cout, kind)
+    with torch.no_grad():
+        conv.weight.copy_(r16(torch.randn(conv.weight.shape, generator=g) / (cin * 9) ** 0.5))
+        conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+    x = r16(torch.randn(n, cin, h, w, generator=g))
+    zin = r16(torch.randn(n, cin, h, w, generator=g))           # pre-activation of x's producer (for the dgrad epilogue)
+    xw = x.clone().requires_grad_(True)
+    wref = conv.weight.detach().contiguous().clone().requires_grad_(True)
+    bref = conv.bias.detach().clone().requires_grad_(True)
+    z = torch_conv(xw, wref, bref, kind)
+    y = z * torch.sigmoid(z)
+    dz_ref = r16(torch.randn(z.shape, generator=g))
+    z.backward(dz_ref)
+
+    conv = conv.to(dev)
+    ctx = L.RunCtx(True, bf16=True)
+    a = ops.Act(rows16(x), n, h, w, z=rows16(zin))
+    out = ops.conv_fwd(a, conv.taps_for(ctx), conv.bias, kind, ops.ACT_SILU, save_z=True)
+    assert out.t.dtype == BF and out.z.dtype == BF
+    assert rel(unrows(out.t, n, out.h, out.w), y) < 4e-3
+    assert rel(unrows(out.z, n, out.h, out.w), z) < 4e-3
+    grads = {conv.weight: L.param_grad_like(conv.weight), conv.bias: torch.zeros_like(conv.bias)}
+    dx = conv.backward(a, (out.h, out.w), rows16(dz_ref), grads, ctx=ctx)
+    assert dx.dtype == BF
+    sp = torch.sigmoid(zin)
+    want_dx = xw.grad * (sp * (1 + zin * (1 - sp)))
+    assert rel(unrows(dx, n, h, w), want_dx) < 4e-3, rel(unrows(dx, n, h, w), want_dx)
+    assert grads[conv.weight].dtype == torch.float32
+    assert rel(grads[conv.weight], wref.grad) < 1e-4, rel(grads[conv.weight], wref.grad)
+    assert rel(grads[conv.bias], bref.grad) < 1e-4, rel(grads[conv.bias], bref.grad)
+
+
+def test_wgrad_bf16_concat_input_and_accumulate(dev, L):
+    """Two-pointer (channel-concat) activation rows, and accumulation into a non-zero gradient buffer."""
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(11)
+    n, c1, c2, cout, h, w = 2, 64, 128, 128, 12, 12
+    x1, x2 = r16(torch.randn(n, c1, h, w, generator=g)), r16(torch.randn(n, c2, h, w, generator=g))
+    dz = r16(torch.randn(n, cout, h, w, generator=g))
+    wref = torch.zeros(cout, c1 + c2, 3, 3, requires_grad=True)
+    F.conv2d(torch.cat((x1, x2), 1), wref, None, padding=1).backward(dz)
+    conv = L.TapConv(c1 + c2, cout, "c3s1").to(dev)
+    a = ops.Act(rows16(x1), n, h, w, t2=rows16(x2))
+    gw = L.param_grad_like(conv.weight)
+    gb = torch.zeros(cout, device=dev)
+    ops.conv_wgrad(rows16(dz), (h, w), a, "c3s1", conv.grad_taps(gw), accumulate=2, dbias=gb)
+    assert rel(gw, wref.grad) < 1e-4, rel(gw, wref.grad)
+    assert rel(gb, dz.sum((0, 2, 3))) < 1e-4
+    ops.conv_wgrad(rows16(dz), (h, w), a, "c3s1", conv.grad_taps(gw), accumulate=1)          # adds a second copy
+    assert rel(gw, 2 * wref.grad) < 1e-4
+
+
+def test_token_linear_grads_bf16(dev, L):
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(5)
+    rows_, K, Oc = 200, 96, 136
+    lin = L.TapLinear(K, Oc)
+    with torch.no_grad():
+        lin.weight.copy_(r16(torch.randn(Oc, K, generator=g) / K ** 0.5))
+    x = r16(torch.randn(rows_, K, generator=g))
+    dy = r16(torch.randn(rows_, Oc, generator=g))
+    res = r16(torch.randn(rows_, K, generator=g))
+    xr = x.clone().requires_grad_(True)
+    wr = lin.weight.detach().clone().requires_grad_(True)
+    br = lin.bias.detach().clone().requires_grad_(True)
+    F.linear(xr, wr, br).backward(dy)
+    lin = lin.to(dev)
+    ctx = L.RunCtx(True, bf16=True)
+    dW, db = torch.zeros(Oc, K, device=dev), torch.zeros(Oc, device=dev)
+    ops.linear_rows_wgrad(dy.cuda().to(BF), x.cuda().to(BF), dW, dbias=db)
+    assert rel(dW, wr.grad) < 1e-4 and rel(db, br.grad) < 1e-4
+    dx = ops.linear_rows_dgrad(dy.cuda().to(BF), lin.weight_t_for(ctx), res=res.cuda().to(BF))
+    assert rel(dx, xr.grad + res) < 4e-3
+
+
+def test_groupnorm_adagn_backward_bf16(dev):
+    """bf16-rows GroupNorm/AdaGN fold + backward against the fp32 kernels on the same (rounded) inputs."""
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(9)
+    n, C_, h, w = 3, 64, 6, 10
+    y = r16(torch.randn(n * h * w, C_, generator=g) * 1.5 + 0.3).cuda()
+    z = r16(torch.randn(n * h * w, C_, generator=g)).cuda()
+    dout = r16(torch.randn(n * h * w, C_, generator=g)).cuda()
+    gamma, beta = (torch.rand(C_, generator=g) + 0.5).cuda(), torch.randn(C_, generator=g).cuda()
+    mod = torch.randn(n, C_, generator=g).cuda()
+    a32 = ops.Act(y, n, h, w)
+    a16 = ops.Act(y.to(BF), n, h, w)
+    s32, h32, m32, r32 = ops.gn_affine(a32, gamma, beta, mod)
+    s16, h16, m16, r16_ = ops.gn_affine(a16, gamma, beta, mod, want_stats=True)
+    assert rel(s16, s32) < 1e-5 and rel(h16, h32) < 1e-5 and rel(m16, m32) < 1e-5 and rel(r16_, r32) < 1e-5
+    dg32, db32, dg16, db16 = (torch.zeros(C_, device=dev) for _ in range(4))
+    dz32, dm32 = ops.gn_adagn_bwd(dout, y, z, n, h * w, gamma, beta, mod, m32, r32, dg32, db32)
+    dz16, dm16 = ops.gn_adagn_bwd(dout.to(BF), y.to(BF), z.to(BF), n, h * w, gamma, beta, mod, m16, r16_, dg16, db16)
+    assert dz16.dtype == BF
+    assert rel(dz16, dz32) < 4e-3, rel(dz16, dz32)
+    assert rel(dm16, dm32) < 1e-4 and rel(dg16, dg32) < 1e-4 and rel(db16, db32) < 1e-4
+
+
+@pytest.mark.parametrize("n,S,heads,dk", [(2, 40, 2, 16), (1, 256, 1, 64), (2, 64, 1, 128)])
+def test_attention_core_backward_bf16(dev, n, S, heads, dk):
+    """dqkv of the bf16 attention core vs the fp32 kernels on the same rounded q, k, v (x12 logits keep the column softmax
+    far from uniform, like the reference-pinned block golden)."""
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(S + dk)
+    qkv = r16(torch.randn(n * S, heads * 3 * dk, generator=g) * 2.0).cuda()
+    dres = r16(torch.randn(n * S, heads * dk, generator=g)).cuda()
+    res32, P32 = ops.attention_core_fwd(qkv, n, S, heads, dk)
+    res16, P16 = ops.attention_core_fwd_bf16(qkv.to(BF), n, S, heads, dk, keep_p=True)
+    assert rel(res16, res32) < 8e-3, rel(res16, res32)
+    d32 = ops.attention_core_bwd(dres, qkv, P32, n, S, heads, dk)
+    d16 = ops.attention_core_bwd_bf16(dres.to(BF), qkv.to(BF), P16, n, S, heads, dk)
+    assert d16.dtype == BF and d16.shape == d32.shape
+    assert rel(d16, d32) < 1.5e-2, rel(d16, d32)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+CASES = ["narrow_cond", "narrow_gain", "deep_uncond", "sr_recon"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_unet_grads_bf16_vs_reference_golden(dev, O, case):
+    """Whole narrow networks: loss and every live gradient tensor of the bf16 training path against the REFERENCE's fp32
+    gradients (tests/golden/model_*.npz, generated by importing the real reference)."""
+    import json
+    from models.U_Net import U_Net
+    z = np.load(os.path.join(GOLDEN, f"model_{case}.npz"))
+    cfg = json.loads(str(z["cfg"]))
+    P = O.seeded_params(cfg, seed=3, gain=float(z["gain"]))
+    net = U_Net(**cfg)
+    net.load_state_dict(P, strict=True)
+    net = net.cuda().set_training_dtype(BF)
+    x, t = T(z["x"]).cuda(), T(z["t"]).cuda()
+    cond = T(z["cond"]).cuda() if "cond" in z.files else None
+    tgt = T(z["target"]).cuda()
+    loss, grads = net.loss_and_grads(x, t if cfg.get("time_dim") is not None else None, cond, tgt)
+    assert abs(float(loss) - float(z["loss"])) < 1e-2 * max(1.0, abs(float(z["loss"])))
+    # the golden keeps the norm of every live gradient and a sample of entries; compare through the fp32 HIP path, which
+    # is itself pinned to the golden by test_unet_grads_golden
+    net32 = U_Net(**cfg)
+    net32.load_state_dict(P, strict=True)
+    net32 = net32.cuda()
+    loss32, grads32 = net32.loss_and_grads(x, t if cfg.get("time_dim") is not None else None, cond, tgt)
+    names = dict(net.named_parameters())
+    names32 = dict(net32.named_parameters())
+    bad = []
+    for k in names:
+        if names[k] not in grads:
+            continue
+        r = rel(grads[names[k]], grads32[names32[k]])
+        # conv biases ahead of a GroupNorm: their true gradient is a cancelling sum (~1e-7 of its terms)
+        if r > 2e-2 and not (".conv_block_" in k and k.endswith("conv_layer.0.bias")):
+            bad.append((k, r))
+    assert not bad, bad[:10]
+
+
+def test_trainer_bf16_follows_fp32(dev, O):
+    """Three optimiser steps of the narrow model: the bf16 trainer's losses stay within 1 % of the fp32 trainer's and
+    the weights move the same way (fp32 master weights: no bf16 round-off accumulates in them)."""
+    import degraders as D
+    from models.U_Net import U_Net
+    from sdm_hip.trainer import DiffusionTrainer
+    cfg = O.full_cfg(dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=32, cond_dim=3, num_layers=2,
+                          attn_layers=[1], num_heads=2, dim_per_head=16, min_channel=32, max_channel=64))
+    P = O.seeded_params(cfg, seed=3, gain=1.8)
+    nets = []
+    for dt in (torch.float32, BF):
+        net = U_Net(**cfg)
+        net.load_state_dict(P, strict=True)
+        nets.append(net.cuda())
+    sched = D.CosineNoiseDegradation(1000)
+    tr32 = DiffusionTrainer(nets[0], sched, lr=1e-3)
+    tr16 = DiffusionTrainer(nets[1], sched, lr=1e-3, train_dtype=BF)
+    g = torch.Generator().manual_seed(2)
+    for i in range(3):
+        x0 = torch.randn(4, 3, 16, 16, generator=g).cuda()
+        eps = torch.randn(4, 3, 16, 16, generator=g).cuda()
+        t = torch.randint(1, 1000, (4,), generator=g).cuda()
+        lab = torch.eye(3)[torch.randint(0, 3, (4,), generator=g)].cuda()
+        l32 = float(tr32.step(x0, lab, eps=eps, t=t))
+        l16 = float(tr16.step(x0, lab, eps=eps, t=t))
+        assert abs(l16 - l32) < 1e-2 * max(1.0, abs(l32)), (i, l16, l32)
+    torch.cuda.synchronize()
+    sd32, sd16 = nets[0].state_dict(), nets[1].state_dict()
+    moved = off = 0
+    for k in sd32:
+        d0 = (sd32[k].cpu() - P[k]).abs()
+        d = (sd16[k].cpu() - sd32[k].cpu()).abs()
+        moved += int((d0 > 1e-4).sum())
+        off += int((d > 1.5e-3).sum())          # more than half an Adam step (lr 1e-3, 3 steps) apart
+    assert moved > 1000 and off / moved < 0.05, (off, moved)
+    # the bf16 weight copies follow the optimizer: a sampling forward in bf16 after training uses fresh copies
+    assert nets[1].training_dtype == BF

@@ -252,3 +252,51 @@ def test_c5_sr_training_step_256(dev, O):
     assert abs(float(loss) - float(ref_loss)) < 2e-5 * max(1.0, abs(float(ref_loss)))
     assert abs(float(loss2) - float(ref_loss)) < 2e-5 * max(1.0, abs(float(ref_loss)))
     assert check_grads(O, cfg, net, grads, ref_g) == 148
+
+
+# ------------------------------------------------------------------------------------------------ C4 / C5 in bf16
+def _check_grads_bf16(O, cfg, net, grads, ref_g, lim=2e-2):
+    """bf16 training path: per-gradient-tensor rel-L2 <= 2e-2 against the fp32 oracle (the reference has no bf16 mode: the
+    rounding itself is parity-unpinned).  Conv biases ahead of a GroupNorm are excluded: their true gradient is a
+    cancelling sum ~1e-7 of its terms, below bf16 resolution of the terms."""
+    dead = set(O.dead_param_names(cfg))
+    bad, n = [], 0
+    for k, p in net.named_parameters():
+        if k in dead or (".conv_block_" in k and k.endswith("conv_layer.0.bias")):
+            continue
+        n += 1
+        r = rel(grads[p], ref_g[k])
+        if r > lim:
+            bad.append((k, r))
+    assert not bad, bad[:10]
+    return n
+
+
+def test_c4_training_step_128_bf16(dev, O):
+    """configs[3] shape on the bf16 training path: loss within 1e-2 relative, gradients within rel-L2 2e-2 of the oracle."""
+    import degraders as D
+    cfg, net, P = standard(O)
+    net.set_training_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(123)
+    x0 = torch.randn(2, 3, 128, 128, generator=g)
+    eps = torch.randn(2, 3, 128, 128, generator=g)
+    t = torch.tensor([901, 88])
+    ref_loss, _, ref_g = O.loss_and_grads(P, cfg, O.CosineSchedule(1000), x0, t, eps, None)
+    x_t = D.CosineNoiseDegradation(1000)(x0.cuda(), t.cuda(), eps.cuda())
+    loss, grads = net.loss_and_grads(x_t, t.cuda(), None, eps.cuda())
+    assert abs(float(loss) - float(ref_loss)) < 1e-2 * max(1.0, abs(float(ref_loss)))
+    assert _check_grads_bf16(O, cfg, net, grads, ref_g) == 148 - 16
+
+
+def test_c5_sr_training_step_256_bf16(dev, O):
+    """configs[4] in the mode BASELINE names it: SR 64->256 training step, in_channel=6, Tanh head, bf16 (attention core at
+    S=4096, d=512 and d=1024 through the bf16 kernels, forward and backward)."""
+    import degraders as D
+    from sdm_hip.trainer import DiffusionTrainer
+    cfg, net, P, x0, eps, t = _sr_setup(O)
+    ref_loss, ref_g = _sr_oracle(O, cfg, P, x0, eps, t)
+    tr = DiffusionTrainer(net, D.CosineNoiseDegradation(1000), lr=0.0, sr=(64, 256, 100), train_dtype=torch.bfloat16)
+    x_in, target = tr.sr_inputs(x0.cuda(), eps.cuda(), t.cuda())
+    loss, grads = net.loss_and_grads(x_in, t.cuda(), None, target)
+    assert abs(float(loss) - float(ref_loss)) < 1e-2 * max(1.0, abs(float(ref_loss)))
+    assert _check_grads_bf16(O, cfg, net, grads, ref_g) == 148 - 16
