@@ -361,9 +361,10 @@ int sdm_transpose_bf16(const uint16_t* src, int64_t ld_src, int64_t src_bs0, int
  * rounded up to 8; concat split a multiple of 8; no pending affine), dw / dbias fp32.  Both operands are K-major row
  * tiles staged by LDS-DMA and read with the transposing LDS read ds_read_b64_tr_b16. */
 int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream);
-/* dst[t][c][r] = bf16(src[t][r][c]) for t < T: transposed bf16 weight copy (tap-major conv weights [tap][c_out][c_in] ->
- * [tap][c_in][c_out]; Linear [O][K] -> [K][O] with T = 1). */
-int sdm_cast_bf16_t(const float* src, uint16_t* dst, int T, int R, int Cc, sdm_stream_t s);
+/* dst[t][c][r] = bf16(src[t][r][c]) for t < T, dst rows of pitch ldd >= R with [R, ldd) zero-filled: transposed bf16 weight
+ * copy (tap-major conv weights [tap][c_out][c_in] -> [tap][c_in][c_out]; Linear [O][K] -> [K][O] with T = 1; the head
+ * conv's 3 output channels padded to ldd = 8, the reduction granule of the bf16 contraction). */
+int sdm_cast_bf16_t(const float* src, uint16_t* dst, int T, int R, int Cc, int ldd, sdm_stream_t s);
 /* sdm_gn_adagn_bwd with dout / y / z / dz as bf16 rows (C %% 8 == 0, C <= 2048); sums, coefficients, dmod / dgamma / dbeta
  * fp32; same zero-filled ws contract. */
 int sdm_gn_adagn_bwd_bf16(const uint16_t* dout, int64_t lddo, const uint16_t* y, int64_t ldy, const uint16_t* z, int64_t ldz,
@@ -386,6 +387,10 @@ int sdm_head_conv_dgrad_bf16(const float* dy_nchw, const float* w_tap, uint16_t*
                              int images, int Cin, int H, int W, int Cout, sdm_stream_t s);
 int sdm_head_conv_wgrad_bf16(const uint16_t* x_nhwc, const float* g_nchw, float* dw_tap, float* dbias, float* ws,
                              int images, int Cin, int H, int W, int Cout, sdm_stream_t s);
+/* NCHW fp32 [images][C][H][W] -> NHWC bf16 rows [images*H*W][Cp], channels [C, Cp) zero (Cp a multiple of 8): the 3- / 6-
+ * channel side of the edge convs in the row format of the matrix-core kernels, whose weight / data gradients then run on
+ * sdm_wgrad_bf16 / sdm_igemm_bf16 (U_Net.py:55-60,121-128 backward). */
+int sdm_nchw_to_rows_bf16(const float* x_nchw, uint16_t* out_rows, int images, int C, int H, int W, int Cp, sdm_stream_t s);
 
 #ifdef __cplusplus
 }

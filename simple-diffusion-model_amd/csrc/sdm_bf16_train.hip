@@ -322,10 +322,11 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
 // dst[t][c][r] = bf16(src[t][r][c]): the transposed bf16 weight copy the data gradient contracts against
 // (tap-major conv weights [tap][c_out][c_in] -> [tap][c_in][c_out]; linear weights [O][K] -> [K][O] with T = 1)
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int R, int Cc) {
+__global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int R, int Cc,
+                                                          int ldd) {
   __shared__ float tile[64][65];
   const float* s = src + (long long)blockIdx.z * R * Cc;
-  bf16_t* o = dst + (long long)blockIdx.z * R * Cc;
+  bf16_t* o = dst + (long long)blockIdx.z * Cc * ldd;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
@@ -335,13 +336,13 @@ __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restric
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
-    if (c < Cc && r < R) o[(long long)c * R + r] = f2bf(tile[tx][i]);
+    if (c < Cc && r < ldd) o[(long long)c * ldd + r] = f2bf(tile[tx][i]);      // r in [R, ldd): zero padding
   }
 }
 
-extern "C" int sdm_cast_bf16_t(const float* src, uint16_t* dst, int T, int R, int Cc, sdm_stream_t s) {
-  SDM_CHECK_ARG(src && dst && T > 0 && R > 0 && Cc > 0, "cast_bf16_t: bad args");
-  hipLaunchKernelGGL(cast_bf16_t_kernel, dim3(cdiv(Cc, 64), cdiv(R, 64), T), dim3(256), 0, (hipStream_t)s, src, dst, R, Cc);
+extern "C" int sdm_cast_bf16_t(const float* src, uint16_t* dst, int T, int R, int Cc, int ldd, sdm_stream_t s) {
+  SDM_CHECK_ARG(src && dst && T > 0 && R > 0 && Cc > 0 && ldd >= R, "cast_bf16_t: bad args");
+  hipLaunchKernelGGL(cast_bf16_t_kernel, dim3(cdiv(Cc, 64), cdiv(ldd, 64), T), dim3(256), 0, (hipStream_t)s, src, dst, R, Cc, ldd);
   SDM_CHECK_LAUNCH("cast_bf16_t");
   return SDM_OK;
 }
@@ -528,5 +529,36 @@ extern "C" int sdm_colsum_bf16(const uint16_t* x, int64_t ldx, int rows, int C, 
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)s, x, (long long)ldx, (long long)rows,
                      C, rpb, out);
   SDM_CHECK_LAUNCH("colsum_bf16");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// NCHW fp32 image / gradient -> NHWC bf16 rows padded to Cp channels (Cp a multiple of 8, pad = 0): puts the 3- or
+// 6-channel side of the edge convolutions (in_layer.0 input, out_layers.1 output gradient) into the row format of the
+// matrix-core kernels, so that their weight / data gradients run on sdm_wgrad_bf16 / sdm_igemm_bf16 like any other conv
+// (the one-wave-per-pixel VALU forms took 9.4 ms + 1.4 ms + 1.0 ms per step at 256x256, batch 8).
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_rows_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int C,
+                                                                int Cp, long long HW, long long P) {
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long long)gridDim.x * 256) {
+    const long long n = p / HW, rem = p - n * HW;
+    for (int c0 = 0; c0 < Cp; c0 += 8) {
+      u16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (c0 + k < C) ? f2bf(x[(n * C + c0 + k) * HW + rem]) : (bf16_t)0;
+      *(u16x8*)(out + p * Cp + c0) = o;
+    }
+  }
+}
+
+extern "C" int sdm_nchw_to_rows_bf16(const float* x_nchw, uint16_t* out_rows, int images, int C, int H, int W, int Cp,
+                                     sdm_stream_t s) {
+  SDM_CHECK_ARG(x_nchw && out_rows && images > 0 && C > 0 && H > 0 && W > 0 && Cp >= C && Cp % 8 == 0 && aligned16(out_rows),
+                "nchw_to_rows_bf16: bad args (Cp must be a multiple of 8 and >= C)");
+  const long long HW = (long long)H * W, P = HW * images;
+  int grid = (int)((P + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(nchw_to_rows_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, x_nchw, out_rows, C, Cp, HW, P);
+  SDM_CHECK_LAUNCH("nchw_to_rows_bf16");
   return SDM_OK;
 }

@@ -217,20 +217,31 @@ class U_Net(nn.Module):
         slab = self._edge_slab(dout.device)
 
         bf = ctx.bf16
-        sfx = "_bf16" if bf else ""
-
-        def head_wgrad():
-            ops.lib.call("sdm_head_conv_wgrad" + sfx, hin.t.data_ptr(), dout.data_ptr(),
-                         head.grad_taps(grads[head.weight]).data_ptr(), grads[head.bias].data_ptr(), slab.data_ptr(), n, hin.c,
-                         H, W, self.out_channel, ops._stream())
-        if ops.SIDE.enabled:           # edge weight gradients ride the side stream too (they share `slab`: same stream)
-            with ops.SIDE.fork(hin.t, dout):
-                head_wgrad()
+        if bf:
+            # bf16 path: the 3-channel gradient becomes NHWC rows padded to 8 channels, and the head conv's gradients run
+            # on the matrix-core kernels like any other conv (weight gradient: M = 3 rows of a 64-row tile; data gradient:
+            # K = 8 of a 64-deep K-step -- wasteful per FLOP, but ~50x faster than the one-wave-per-pixel forms at 256x256)
+            dy8 = ops.nchw_to_rows_bf16(dout, 8)
+            gw = head.grad_taps(grads[head.weight])
+            if ops.SIDE.enabled:
+                with ops.SIDE.fork(hin.t, dy8):
+                    ops.conv_wgrad(dy8[:, :self.out_channel], (H, W), hin, "c3s1", gw, dbias=grads[head.bias])
+            else:
+                ops.conv_wgrad(dy8[:, :self.out_channel], (H, W), hin, "c3s1", gw, dbias=grads[head.bias])
+            dz = ops.conv_dgrad(dy8, (H, W), head.taps_t_for(ctx), "c3s1", (H, W), n, dact_z=hin.z)
         else:
-            head_wgrad()
-        dz = torch.empty_like(hin.t)
-        ops.lib.call("sdm_head_conv_dgrad" + sfx, dout.data_ptr(), head.taps().data_ptr(), dz.data_ptr(), hin.z.data_ptr(), n,
-                     hin.c, H, W, self.out_channel, st)
+            def head_wgrad():
+                ops.lib.call("sdm_head_conv_wgrad", hin.t.data_ptr(), dout.data_ptr(),
+                             head.grad_taps(grads[head.weight]).data_ptr(), grads[head.bias].data_ptr(), slab.data_ptr(), n,
+                             hin.c, H, W, self.out_channel, ops._stream())
+            if ops.SIDE.enabled:       # edge weight gradients ride the side stream too (they share `slab`: same stream)
+                with ops.SIDE.fork(hin.t, dout):
+                    head_wgrad()
+            else:
+                head_wgrad()
+            dz = torch.empty_like(hin.t)
+            ops.lib.call("sdm_head_conv_dgrad", dout.data_ptr(), head.taps().data_ptr(), dz.data_ptr(), hin.z.data_ptr(), n,
+                         hin.c, H, W, self.out_channel, st)
         dz = self.out_layers[0].backward(ctx, dz, grads)                 # -> dz of the last up-sampler
         user_hook = getattr(self, "_block_done_hook", None)
 
@@ -255,15 +266,25 @@ class U_Net(nn.Module):
         dz = self.in_layer[1].backward(ctx, dz, grads)
         stem = self.in_layer[0].conv_layer.conv
         x = ctx.rec["x"]
-        def stem_wgrad():
-            ops.lib.call("sdm_stem_conv_wgrad" + sfx, x.data_ptr(), dz.data_ptr(), stem.grad_taps(grads[stem.weight]).data_ptr(),
-                         grads[stem.bias].data_ptr(), slab.data_ptr(), x.shape[0], x.shape[1], x.shape[2], x.shape[3],
-                         stem.cout, ops._stream())
-        if ops.SIDE.enabled:
-            with ops.SIDE.fork(x, dz):
-                stem_wgrad()
+        if bf:
+            x8 = ops.nchw_to_rows_bf16(x, 8)
+            xa = ops.Act(x8[:, :x.shape[1]], x.shape[0], x.shape[2], x.shape[3])
+            gw = stem.grad_taps(grads[stem.weight])
+            if ops.SIDE.enabled:
+                with ops.SIDE.fork(x8, dz):
+                    ops.conv_wgrad(dz, (x.shape[2], x.shape[3]), xa, "c3s1", gw, dbias=grads[stem.bias])
+            else:
+                ops.conv_wgrad(dz, (x.shape[2], x.shape[3]), xa, "c3s1", gw, dbias=grads[stem.bias])
         else:
-            stem_wgrad()
+            def stem_wgrad():
+                ops.lib.call("sdm_stem_conv_wgrad", x.data_ptr(), dz.data_ptr(), stem.grad_taps(grads[stem.weight]).data_ptr(),
+                             grads[stem.bias].data_ptr(), slab.data_ptr(), x.shape[0], x.shape[1], x.shape[2], x.shape[3],
+                             stem.cout, ops._stream())
+            if ops.SIDE.enabled:
+                with ops.SIDE.fork(x, dz):
+                    stem_wgrad()
+            else:
+                stem_wgrad()
         hook("in_layer")
         if self.cond_emb is not None:
             if ctx.dmods is not None:

@@ -55,7 +55,7 @@ class RunCtx:
 MATERIALIZE_TRAIN = [os.environ.get("SDM_TRAIN_MATERIALIZE", "1") != "0"]
 
 
-def bf16_weight(mod, key, src_fn, transposed=False):
+def bf16_weight(mod, key, src_fn, transposed=False, pad_to=1):
     """bf16 copy of a contraction weight, refreshed IN PLACE when the fp32 master changed (in-place torch updates bump
     ``_version``; the fused optimizer, which writes through raw pointers, bumps ops.WEIGHT_EPOCH) -- the copy keeps its
     address, so captured graphs stay valid.  ``transposed``: [T, R, C] -> [T, C, R] (what a bf16 data gradient reads)."""
@@ -65,8 +65,10 @@ def bf16_weight(mod, key, src_fn, transposed=False):
     hit = cache.get(key)
     if hit is None or hit[0] != tag:
         keep = hit[1] if (hit is not None and hit[0][0] == tag[0]) else None
-        fn = ops.to_bf16_t if transposed else ops.to_bf16
-        cache[key] = hit = (tag, fn(src_fn(), out=keep))
+        if transposed:
+            cache[key] = hit = (tag, ops.to_bf16_t(src_fn(), out=keep, pad_to=pad_to))
+        else:
+            cache[key] = hit = (tag, ops.to_bf16(src_fn(), out=keep))
     return hit[1]
 
 
@@ -163,8 +165,9 @@ class TapConv(nn.Module):
         return bf16_weight(self, "taps", self.taps) if ctx.bf16 else self.taps()
 
     def taps_t_for(self, ctx):
-        """Weights for the data gradient: fp32 taps (read K-major) or the transposed bf16 copy [taps, c_in, c_out]."""
-        return bf16_weight(self, "taps_t", self.taps, transposed=True) if ctx.bf16 else self.taps()
+        """Weights for the data gradient: fp32 taps (read K-major) or the transposed bf16 copy [taps, c_in, c_out] (c_out
+        zero-padded to a multiple of 8, the reduction granule: only the 3-channel head conv needs the padding)."""
+        return bf16_weight(self, "taps_t", self.taps, transposed=True, pad_to=8) if ctx.bf16 else self.taps()
 
     def grad_taps(self, g):
         v = self._tapview(g)

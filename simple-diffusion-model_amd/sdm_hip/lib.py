@@ -132,7 +132,7 @@ _PROTOS = {
     "sdm_transpose_bf16": (_i, [fp, _i64, _i64, _i64, _i, fp, _i64, _i64, _i, _i, _i, fp]),
     # bf16 training path
     "sdm_wgrad_bf16": (_i, [C.POINTER(WgradDesc), fp]),
-    "sdm_cast_bf16_t": (_i, [fp, fp, _i, _i, _i, fp]),
+    "sdm_cast_bf16_t": (_i, [fp, fp, _i, _i, _i, _i, fp]),
     "sdm_gn_adagn_bwd_bf16": (_i, [fp, _i64, fp, _i64, fp, _i64, _i, _i, _i, _i, fp, fp, fp, _i, fp, fp, fp, _i64,
                                    fp, fp, fp, fp, fp, fp]),
     "sdm_col_softmax_bwd_bf16": (_i, [fp, _i64, fp, _i64, fp, _i64, _i, _i, _f, fp]),
@@ -141,6 +141,7 @@ _PROTOS = {
     "sdm_stem_conv_wgrad_bf16": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "sdm_head_conv_dgrad_bf16": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "sdm_head_conv_wgrad_bf16": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "sdm_nchw_to_rows_bf16": (_i, [fp, fp, _i, _i, _i, _i, _i, fp]),
 }
 EXPORTS = tuple(_PROTOS)
 

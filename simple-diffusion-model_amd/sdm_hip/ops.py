@@ -224,14 +224,25 @@ def to_bf16(t, out=None):
     return out
 
 
-def to_bf16_t(w3, out=None):
-    """Transposed bf16 copy of a contiguous fp32 [T, R, C] tensor -> [T, C, R] (the weight layout a bf16 DATA gradient
-    contracts against: tap-major conv weights [tap][c_out][c_in] -> [tap][c_in][c_out]; Linear [O][K] -> [1][K][O])."""
+def to_bf16_t(w3, out=None, pad_to=1):
+    """Transposed bf16 copy of a contiguous fp32 [T, R, C] tensor -> [T, C, Rp] (the weight layout a bf16 DATA gradient
+    contracts against: tap-major conv weights [tap][c_out][c_in] -> [tap][c_in][c_out]; Linear [O][K] -> [1][K][O]).
+    Rp = R rounded up to ``pad_to`` (zero-filled): the reduction granule of the bf16 contraction is 8."""
     T, R, C_ = w3.shape
     assert w3.is_contiguous()
+    Rp = (R + pad_to - 1) // pad_to * pad_to
     if out is None:
-        out = torch.empty((T, C_, R), dtype=BF16, device=w3.device)
-    lib.call("sdm_cast_bf16_t", _p(w3), _p(out), T, R, C_, _stream())
+        out = torch.empty((T, C_, Rp), dtype=BF16, device=w3.device)
+    lib.call("sdm_cast_bf16_t", _p(w3), _p(out), T, R, C_, Rp, _stream())
+    return out
+
+
+def nchw_to_rows_bf16(x, cp=8):
+    """NCHW fp32 [n, c, h, w] -> NHWC bf16 rows [n*h*w, cp] (channels [c, cp) zero): the image side of the edge convs in
+    the row format of the matrix-core kernels."""
+    n, c, h, w = x.shape
+    out = torch.empty((n * h * w, cp), dtype=BF16, device=x.device)
+    lib.call("sdm_nchw_to_rows_bf16", _p(x), _p(out), n, c, h, w, cp, _stream())
     return out
 
 
