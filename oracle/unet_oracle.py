@@ -315,13 +315,13 @@ def ddim_steps(min_noise, max_noise, step):
     return steps
 
 
-def ddim_sample(P, cfg, sched, x_t, min_noise=1, max_noise=1000, step=10, labels=None):
+def ddim_sample(P, cfg, sched, x_t, min_noise=1, max_noise=1000, step=10, labels=None, cond_img=None):
     steps = ddim_steps(min_noise, max_noise, step)
     traj = []
     with torch.no_grad():
         for c, s in enumerate(steps):
             t = torch.tensor([s])
-            eps = unet_forward(P, cfg, x_t, t, labels)
+            eps = unet_forward(P, cfg, x_t if cond_img is None else torch.cat((x_t, cond_img), dim=1), t, labels)
             abar = sched.params(t)[2]
             x0 = (1 / abar ** 0.5) * (x_t - (1 - abar) ** 0.5 * eps)
             if c < len(steps) - 1:
@@ -376,10 +376,15 @@ class OracleTrainer:
         self.P = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
         self.opt = torch.optim.Adam(list(self.P.values()), lr=lr, betas=(0.5, 0.999))
 
-    def step(self, x0, t, eps, labels=None):
+    def step(self, x0, t, eps, labels=None, target="eps", cond_img=None):
+        """target "eps": train_diffusion.py:343-352; "x0": cold diffusion, train_noise_cold_diffusion.py:335-342;
+        cond_img: doodle, the label image concatenated to x_t (train_doodle_diffusion.py:304)."""
         self.opt.zero_grad()
-        out = unet_forward(self.P, self.cfg, q_sample(self.sched, x0, t, eps), t, labels)
-        loss = F.mse_loss(out, eps)
+        x_t = q_sample(self.sched, x0, t, eps)
+        if cond_img is not None:
+            x_t = torch.cat((x_t, cond_img), dim=1)
+        out = unet_forward(self.P, self.cfg, x_t, t, labels)
+        loss = F.mse_loss(out, eps if target == "eps" else x0)
         loss.backward()
         self.opt.step()
-        return float(loss)
+        return float(loss.detach())

@@ -83,6 +83,67 @@ class ConditionalImgDataset(Dataset):
         return _load_bgr(path), torch.Tensor(labels)
 
 
+class DoodleImgDataset(Dataset):
+    """(image, label image) pairs (custom_dataset/doodle_dataset.py:14-66): the same TinyDB file layout as the conditional
+    dataset, the FIRST entry of the "Labels" list naming the key that holds the label image's path."""
+
+    def __init__(self, dataset_path=None):
+        import random
+        with open(dataset_path) as f:
+            db = json.load(f)
+        data_tbl, labels_tbl = db.get("Data", {}), db.get("Labels", {})
+        if len(data_tbl) <= 0:
+            raise Exception("No data found in Data table.")
+        if len(labels_tbl) <= 0:
+            raise Exception("No data found in Labels table.")
+        by_id = lambda tbl: [tbl[k] for k in sorted(tbl, key=lambda s: int(s))]
+        self.all_labels = by_id(labels_tbl)[0]["labels"]
+        self.all_data = by_id(data_tbl)
+        random.shuffle(self.all_data)
+        self.root = os.path.dirname(os.path.abspath(dataset_path))
+        label = self.all_labels[0]
+        self.dataset = [(d["filename"], d[label]) for d in self.all_data]
+
+    def get_labels(self):
+        return self.all_labels
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def _path(self, p):
+        return p if (os.path.isabs(p) or os.path.exists(p)) else os.path.join(self.root, p)
+
+    def __getitem__(self, i):
+        if len(self.dataset) <= 0:
+            raise Exception("No data found in dataset.")
+        img, lab = self.dataset[i]
+        return _load_bgr(self._path(img)), _load_bgr(self._path(lab))
+
+
+class SyntheticPairDataset(Dataset):
+    """``synthetic-pairs:N:C:H:W``: seeded Gaussian (image, label image) pairs (doodle smoke tests)."""
+
+    def __init__(self, spec):
+        _, n, c, h, w = spec.split(":")
+        self.shape, self.n = (int(c), int(h), int(w)), int(n)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(4321 + i)
+        return torch.randn(self.shape, generator=g), torch.randn(self.shape, generator=g)
+
+    def get_labels(self):
+        return ["label_img"]
+
+
+def open_pair_dataset(dataset_path):
+    if isinstance(dataset_path, str) and dataset_path.startswith("synthetic-pairs:"):
+        return SyntheticPairDataset(dataset_path)
+    return DoodleImgDataset(dataset_path)
+
+
 def open_dataset(dataset_path, use_conditional, cond_dim=None):
     if isinstance(dataset_path, str) and dataset_path.startswith("synthetic:"):
         return SyntheticDataset(dataset_path, cond_dim if use_conditional else None)

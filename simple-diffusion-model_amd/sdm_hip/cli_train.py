@@ -11,7 +11,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL ac
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from custom_dataset.img_dataset import open_dataset
+from custom_dataset.img_dataset import open_dataset, open_pair_dataset
 from degraders import CosineNoiseDegradation, NoiseDegradation
 from diffusion_enums import DiffusionAlg, NoiseScheduler
 from diffusion_sampling_algorithms import cold_diffusion_sampling, ddim_sampling, ddpm_sampling
@@ -43,9 +43,17 @@ def _save(out_dir, net, opt, steps, starting_epoch, linear, beta_1, beta_T):
                dest_path=out_dir, checkpoint=True, steps=steps)
 
 
-def run_training(sr=False):
-    """Shared body of train_diffusion.py (sr=False) and train_SR_diffusion.py (sr=True)."""
-    project_name = "Diffusion"
+PROJECT = {"diffusion": "Diffusion", "sr": "Diffusion", "cold": "Noise-Cold-Diffusion", "doodle": "Doodle-Diffusion"}   # log file names
+
+
+def run_training(sr=False, mode=None):
+    """Shared body of the four trainers: train_diffusion.py ("diffusion"), train_SR_diffusion.py ("sr"),
+    train_noise_cold_diffusion.py ("cold": x0 target, cold sampler for the plots) and train_doodle_diffusion.py ("doodle":
+    image-conditioned, the label image is concatenated to x_t on the channel axis)."""
+    mode = mode or ("sr" if sr else "diffusion")
+    sr = mode == "sr"
+    cold, doodle = mode == "cold", mode == "doodle"
+    project_name = PROJECT[mode]
     parser = argparse.ArgumentParser(description="Train Diffusion models.")
     parser.add_argument("-c", "--config-path", help="File path to load json config file.", required=True, type=pathlib.Path)
     parser.add_argument("--device", help="Which hardware device will model run on (default='cpu')?", choices=["cpu", "cuda"],
@@ -56,13 +64,17 @@ def run_training(sr=False):
 
     with open(args["config_path"], "r") as f:
         cfg = json.loads(f.read())
-    for k in REQUIRED_KEYS + (SR_KEYS if sr else []):   # the reference indexes every key without defaults -> KeyError
+    required = [k for k in REQUIRED_KEYS if not (doodle and k in ("use_conditional", "flip_imgs"))]
+    for k in required + (SR_KEYS if sr else []):        # the reference indexes every key without defaults -> KeyError
         cfg[k]
+    if doodle:                                           # train_doodle_diffusion.py has neither switch
+        cfg.setdefault("use_conditional", False)
+        cfg.setdefault("flip_imgs", False)
     if cfg["dataset_path"] is None:
         raise ValueError("No dataset_path entered.")
     if cfg["noise_scheduler"] not in (NoiseScheduler.LINEAR.name, NoiseScheduler.COSINE.name):
         raise ValueError("Invalid noise scheduler type.")
-    if not sr and cfg["diffusion_alg"] not in (DiffusionAlg.DDIM.name, DiffusionAlg.DDPM.name):
+    if not sr and not cold and cfg["diffusion_alg"] not in (DiffusionAlg.DDIM.name, DiffusionAlg.DDPM.name):
         raise ValueError("Invalid diffusion algorithm type.")
     linear = cfg["noise_scheduler"] == NoiseScheduler.LINEAR.name
     beta_1, beta_T = (cfg["beta1"], cfg["betaT"]) if linear else (None, None)
@@ -91,12 +103,15 @@ def run_training(sr=False):
     if cfg.get("seed") is not None:
         torch.manual_seed(cfg["seed"])
 
-    dataset = open_dataset(cfg["dataset_path"], cfg["use_conditional"], cfg["cond_dim"])
+    dataset = open_pair_dataset(cfg["dataset_path"]) if doodle else \
+        open_dataset(cfg["dataset_path"], cfg["use_conditional"], cfg["cond_dim"])
     sampler = torch.utils.data.distributed.DistributedSampler(dataset, world, rank, shuffle=True) if world > 1 else None
     loader = torch.utils.data.DataLoader(dataset, batch_size=cfg["batch_size"], num_workers=4, shuffle=sampler is None,
                                          sampler=sampler, drop_last=world > 1, pin_memory=True)
     plot_batch = next(iter(torch.utils.data.DataLoader(dataset, batch_size=cfg["plot_img_count"], num_workers=0, shuffle=False)))
-    plot_imgs, plot_labels = (plot_batch if cfg["use_conditional"] else (plot_batch, None))
+    plot_imgs, plot_labels = (plot_batch if (cfg["use_conditional"] or doodle) else (plot_batch, None))
+    if doodle and chief:                                  # train_doodle_diffusion.py:146-149
+        plot_sampled_images(sampled_imgs=plot_labels, file_name="label_plot", dest_path=out_dir)
     if cfg["use_conditional"] and chief:
         with open(os.path.join(out_dir, "labels.txt"), "a") as f:
             csv.writer(f).writerows([dataset.get_labels()] + plot_labels.cpu().tolist())
@@ -125,7 +140,9 @@ def run_training(sr=False):
     schedule = _schedule(cfg, beta_1, beta_T, dev)
     trainer = DiffusionTrainer(net, schedule, lr=cfg["diffusion_lr"], betas=(0.5, 0.999), min_noise_step=lo,
                                max_actual_noise_step=hi_act, seed=cfg.get("seed"),
-                               sr=(cfg["lr_dim"], cfg["sr_dim"], cfg["cond_t"]) if sr else None)
+                               sr=(cfg["lr_dim"], cfg["sr_dim"], cfg["cond_t"]) if sr else None,
+                               objective="x0" if cold else "eps",
+                               train_dtype=torch.bfloat16 if cfg.get("train_dtype") == "bf16" else None)
     opt = trainer.opt
     if ckpt is not None and cfg["load_diffusion_optim"]:
         opt.load_state_dict(ckpt["optimizer"])
@@ -149,7 +166,10 @@ def run_training(sr=False):
         total, count = 0.0, 0
         for index, data in enumerate(loader):
             count += 1
-            if cfg["use_conditional"]:
+            cond_img = None
+            if doodle:
+                x0, labels, cond_img = data[0].to(dev, non_blocking=True), None, data[1].to(dev, non_blocking=True).float()
+            elif cfg["use_conditional"]:
                 x0, labels = data[0].to(dev, non_blocking=True), data[1].to(dev, non_blocking=True).float()
             else:
                 x0, labels = data.to(dev, non_blocking=True), None
@@ -157,7 +177,7 @@ def run_training(sr=False):
             if cfg["flip_imgs"]:                   # per-image horizontal flip with p = 0.5 (:312-314)
                 flip = torch.rand(x0.shape[0], device=dev, generator=trainer.gen) < 0.5     # per-rank stream
                 x0 = torch.where(flip[:, None, None, None], x0.flip(-1), x0)
-            loss = trainer.step(x0, labels)
+            loss = trainer.step(x0, labels, cond_img=cond_img)
             if world > 1:                          # global mean loss; a NaN on any rank reaches every rank, so all ranks
                 dist.all_reduce(loss)              # raise together instead of leaving peers blocked in the next all-reduce
                 loss = loss / world
@@ -183,15 +203,25 @@ def run_training(sr=False):
                                                     min_noise=lo, max_noise=hi_act, cond_img=cond, labels_tensor=lab,
                                                     skip_step_size=skip, device=dev, log=print)
                     plot_sampled_images(sampled_imgs=delta + low, file_name=f"diffusion_plot_{global_steps}", dest_path=out_dir)
+                elif cold:                         # train_noise_cold_diffusion.py:391-419
+                    noise = torch.randn((n_plot, C, H, W), device=dev)
+                    x_plot = schedule(plot_imgs.to(dev).float(), torch.tensor([hi_act], device=dev), noise) if hi_act < hi \
+                        else 1 * noise
+                    lab = plot_labels.to(dev).float() if plot_labels is not None else None
+                    imgs = cold_diffusion_sampling(diffusion_net=net, noise_degradation=schedule, x_t=x_plot, noise=noise,
+                                                   min_noise=lo, max_noise=hi_act, cond_img=None, labels_tensor=lab,
+                                                   skip_step_size=skip, device=dev, log=print)
+                    plot_sampled_images(sampled_imgs=imgs, file_name=f"diffusion_plot_{global_steps}", dest_path=out_dir)
                 elif hi_act < hi:
                     x_plot = schedule(plot_imgs.to(dev).float(), torch.tensor([hi_act], device=dev),
                                       torch.randn((n_plot, C, H, W), device=dev))
                 else:
                     x_plot = torch.randn((n_plot, C, H, W), device=dev)
-                if not sr:
+                if not sr and not cold:
                     lab = plot_labels.to(dev).float() if plot_labels is not None else None
                     common = dict(diffusion_net=net, noise_degradation=schedule, x_t=x_plot, min_noise=lo, max_noise=hi_act,
-                                  cond_img=None, labels_tensor=lab, device=dev, log=print)
+                                  cond_img=lab if doodle else None, labels_tensor=None if doodle else lab, device=dev,
+                                  log=print)
                     if cfg["diffusion_alg"] == DiffusionAlg.DDPM.name:
                         imgs = ddpm_sampling(**common)
                     else:

@@ -87,11 +87,17 @@ class FusedAdam:
 
 class DiffusionTrainer:
     def __init__(self, net, schedule, lr=2e-5, betas=(0.5, 0.999), min_noise_step=1, max_actual_noise_step=1000,
-                 bucket_mb=64, process_group=None, seed=None, use_graph=None, sr=None, train_dtype=None):
+                 bucket_mb=64, process_group=None, seed=None, use_graph=None, sr=None, train_dtype=None, objective="eps"):
         """``sr=(lr_dim, sr_dim, cond_t)`` switches to the super-resolution objective of train_SR_diffusion.py:318-374:
         the net sees cat(q(x0, t), q(lowres(x0), cond_t)) and regresses x0 - lowres(x0).
         ``train_dtype=torch.bfloat16`` runs forward/backward in bf16 storage (U_Net.set_training_dtype); weights,
-        gradients and Adam stay fp32."""
+        gradients and Adam stay fp32.
+        ``objective``: "eps" regresses the noise (train_diffusion.py:343-352, train_doodle_diffusion.py:300-312); "x0"
+        regresses the clean image (cold diffusion, train_noise_cold_diffusion.py:335-342).  An image condition (doodle:
+        ``cat((x_t, lbl_data), 1)``, train_doodle_diffusion.py:304) is passed per step as ``cond_img``."""
+        if objective not in ("eps", "x0"):
+            raise ValueError("objective must be 'eps' or 'x0'")
+        self.objective = objective
         self.sr = sr
         if train_dtype is not None:
             net.set_training_dtype(train_dtype)
@@ -177,11 +183,14 @@ class DiffusionTrainer:
         x_t = ops.q_sample(x0, eps, self.schedule.alpha_bar_of(t))
         return torch.cat((x_t, ops.q_sample(low, eps, abar_c)), dim=1), x0 - low
 
-    def _body(self, x0, labels, eps, t, hyper=None):
+    def _body(self, x0, labels, eps, t, hyper=None, cond_img=None):
         if self.sr is not None:
             x_t, target = self.sr_inputs(x0, eps, t)
         else:
-            x_t, target = ops.q_sample(x0, eps, self.schedule.alpha_bar_of(t)), eps
+            x_t = ops.q_sample(x0, eps, self.schedule.alpha_bar_of(t))
+            target = eps if self.objective == "eps" else x0
+        if cond_img is not None:
+            x_t = torch.cat((x_t, cond_img.to(torch.float32)), dim=1)
         if getattr(self, "_cleared", 0) != self.flat.numel():
             self.flat.zero_()                           # first step, or the previous one did not finish: start clean
         self._cleared = 0                               # backward accumulates (split-K atomics, column sums)
@@ -196,14 +205,14 @@ class DiffusionTrainer:
         torch.cuda.current_stream(self.dev).wait_stream(self.opt_stream)   # next forward sees the updated weights
         return loss
 
-    def step(self, x0, labels=None, eps=None, t=None):
+    def step(self, x0, labels=None, eps=None, t=None, cond_img=None):
         """One optimiser step on the local mini-batch; returns the loss tensor ([1], device)."""
         if eps is None or t is None:
             eps, t = self.draw(x0)
         x0 = x0.contiguous()
         self.opt.step_count += 1
-        if not self.use_graph:
-            return self._body(x0, labels, eps, t)
+        if not self.use_graph or cond_img is not None:
+            return self._body(x0, labels, eps, t, cond_img=cond_img)
         key = (tuple(x0.shape), None if labels is None else tuple(labels.shape))
         if self.g_key != key:
             if self.hyper is None:

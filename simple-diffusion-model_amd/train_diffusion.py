@@ -8,7 +8,8 @@ Differences, all additive:
   * launched under ``torchrun`` (WORLD_SIZE > 1) it trains data-parallel: each rank takes a disjoint shard of
     every epoch, gradients are all-reduced over RCCL, rank 0 alone writes checkpoints / plots / logs;
   * ``dataset_path`` may be ``synthetic:N:C:H:W``.
-Optional extra config keys (ignored by the reference): ``seed``.
+Optional extra config keys (ignored by the reference): ``seed``; ``"train_dtype": "bf16"`` selects the bf16 training path
+(bf16 activations / contraction weight copies, fp32 master weights, gradients and Adam).
 """
 from sdm_hip.cli_train import run_training
 

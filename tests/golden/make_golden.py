@@ -343,10 +343,153 @@ def sr_case():
     print("sr losses", losses)
 
 
+def _params_sample(m, out):
+    for i, (k, v) in enumerate(m.state_dict().items()):
+        v = v.double().flatten()
+        idx = sample_idx(v.numel(), i)
+        out[f"pidx/{k}"] = idx
+        out[f"pval/{k}"] = v[idx].float().numpy()
+
+
+COLD_CFG = dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=32, cond_dim=3, num_layers=2, attn_layers=[1],
+                num_heads=2, dim_per_head=16, min_channel=32, max_channel=64, image_recon=True)
+DOODLE_CFG = dict(num_resnet_blocks=1, in_channel=6, out_channel=3, time_dim=32, cond_dim=None, num_layers=2,
+                  attn_layers=[0], num_heads=1, dim_per_head=None, min_channel=32, max_channel=64)
+
+
+def cold_and_doodle_cases():
+    """Two Adam steps each of the cold-diffusion step body (train_noise_cold_diffusion.py:307-348: x0 target, labels,
+    Tanh head) and of the doodle step body (train_doodle_diffusion.py:283-320: cat((x_t, lbl_data), 1), noise target), plus
+    a doodle DDIM run with the label image as ``cond_img`` (train_doodle_diffusion.py:398-410)."""
+    F = torch.nn.functional
+    cos = RD.CosineNoiseDegradation(1000)
+    g = torch.Generator().manual_seed(41)
+    out = {"cold/cfg": json.dumps(COLD_CFG), "doodle/cfg": json.dumps(DOODLE_CFG)}
+    # ---- cold
+    cfg = O.full_cfg(COLD_CFG)
+    m = ref_model(cfg, O.seeded_params(cfg, seed=3, gain=1.8))
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=2e-3, betas=(0.5, 0.999))
+    losses = []
+    for i in range(2):
+        x0 = torch.tanh(torch.randn(4, 3, 16, 16, generator=g))
+        eps = torch.randn(4, 3, 16, 16, generator=g)
+        t = torch.randint(1, 1000, (4,), generator=g)
+        lab = torch.eye(3)[torch.randint(0, 3, (4,), generator=g)]
+        opt.zero_grad()
+        loss = F.mse_loss(m(cos(x0, t, eps), t, lab), x0)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        out[f"cold/x0_{i}"], out[f"cold/eps_{i}"], out[f"cold/t_{i}"], out[f"cold/lab_{i}"] = (
+            x0.numpy(), eps.numpy(), t.numpy(), lab.numpy())
+    out["cold/losses"] = np.array(losses)
+    sub = {}
+    _params_sample(m, sub)
+    out.update({"cold/" + k: v for k, v in sub.items()})
+    print("cold losses", losses)
+    # ---- doodle
+    cfg = O.full_cfg(DOODLE_CFG)
+    m = ref_model(cfg, O.seeded_params(cfg, seed=3, gain=1.8))
+    m.eval()
+    quiet = lambda *a, **k: None
+    xT = torch.randn(2, 3, 16, 16, generator=g)
+    lbl = torch.tanh(torch.randn(2, 3, 16, 16, generator=g))
+    x_end = RS.ddim_sampling(m, cos, 1 * xT, min_noise=1, max_noise=1000, cond_img=lbl, labels_tensor=None,
+                             ddim_step_size=250, log=quiet)
+    out["doodle/samp_xT"], out["doodle/samp_lbl"], out["doodle/samp_out"] = xT.numpy(), lbl.numpy(), x_end.detach().numpy()
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=2e-3, betas=(0.5, 0.999))
+    losses = []
+    for i in range(2):
+        x0 = torch.randn(4, 3, 16, 16, generator=g)
+        lb = torch.tanh(torch.randn(4, 3, 16, 16, generator=g))
+        eps = torch.randn(4, 3, 16, 16, generator=g)
+        t = torch.randint(1, 1000, (4,), generator=g)
+        opt.zero_grad()
+        loss = F.mse_loss(m(torch.cat((cos(x0, t, eps), lb), dim=1), t, None), eps)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        out[f"doodle/x0_{i}"], out[f"doodle/lbl_{i}"], out[f"doodle/eps_{i}"], out[f"doodle/t_{i}"] = (
+            x0.numpy(), lb.numpy(), eps.numpy(), t.numpy())
+    out["doodle/losses"] = np.array(losses)
+    sub = {}
+    _params_sample(m, sub)
+    out.update({"doodle/" + k: v for k, v in sub.items()})
+    print("doodle losses", losses)
+    np.savez(os.path.join(HERE, "cold_doodle.npz"), **out)
+
+
+CKPT_CFG = dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=32, cond_dim=2, num_layers=1, attn_layers=[0],
+                num_heads=1, dim_per_head=None, min_channel=32, max_channel=32)
+
+
+def checkpoint_case():
+    """A checkpoint written the way the REAL reference writes it -- torch.save({"model": state_dict, "optimizer":
+    Adam.state_dict()}) (train_diffusion.py:384-395, utils/utils.py:67-95) after one optimiser step of the reference
+    model -- a config checkpoint ({"starting_epoch", "global_steps"}, train_diffusion.py:375-383), and the inference
+    config.json that export_models.py:72-99 derives from a training config.  Plus what the reference produces from it:
+    the forward on a fixed input and the parameters after ONE more Adam step resumed from the saved optimizer state."""
+    cfg = O.full_cfg(CKPT_CFG)
+    m = ref_model(cfg, O.seeded_params(cfg, seed=7, gain=1.8))
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=2e-3, betas=(0.5, 0.999))
+    cos = RD.CosineNoiseDegradation(1000)
+    g = torch.Generator().manual_seed(51)
+    F = torch.nn.functional
+
+    def step():
+        x0 = torch.randn(4, 3, 8, 8, generator=g)
+        eps = torch.randn(4, 3, 8, 8, generator=g)
+        t = torch.randint(1, 1000, (4,), generator=g)
+        lab = torch.eye(2)[torch.randint(0, 2, (4,), generator=g)]
+        opt.zero_grad()
+        loss = F.mse_loss(m(cos(x0, t, eps), t, lab), eps)
+        loss.backward()
+        opt.step()
+        return x0, eps, t, lab, float(loss)
+
+    step()
+    d = os.path.join(HERE, "ref_checkpoint")
+    os.makedirs(d, exist_ok=True)
+    torch.save({"model": m.state_dict(), "optimizer": opt.state_dict()}, os.path.join(d, "diffusion_1.pt"))
+    torch.save({"starting_epoch": 0, "global_steps": 1}, os.path.join(d, "config_1.pt"))
+    train_cfg = dict(in_channel=3, out_channel=3, num_layers=1, num_resnet_block=1, attn_layers=[0], attn_heads=1,
+                     attn_dim_per_head=None, time_dim=32, cond_dim=2, min_channel=32, max_channel=32, img_recon=False,
+                     min_noise_step=1, max_noise_step=1000, noise_scheduler="COSINE")
+    entry = {"model_name": "diffusion_1.pt", "img_C": 3, "img_H": 8, "img_W": 8}                  # export_models.py:72-92
+    entry.update({k: train_cfg[k] for k in ("in_channel", "out_channel", "num_layers", "num_resnet_block", "attn_layers",
+                                            "attn_heads", "attn_dim_per_head", "time_dim", "cond_dim", "min_channel",
+                                            "max_channel")})
+    entry.update(image_recon=train_cfg["img_recon"], max_noise=train_cfg["max_noise_step"],
+                 min_noise=train_cfg["min_noise_step"], noise_scheduler=train_cfg["noise_scheduler"])
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump({"models": [entry]}, f)
+    out = {}
+    m.eval()
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    with torch.no_grad():
+        out["fwd_x"], out["fwd_t"], out["fwd_lab"] = x.numpy(), np.array([400, 20]), np.eye(2, dtype=np.float32)
+        out["fwd_y"] = m(x, torch.tensor([400, 20]), torch.eye(2)).numpy()
+    m.train()
+    x0, eps, t, lab, loss = step()
+    out["x0"], out["eps"], out["t"], out["lab"], out["loss"] = x0.numpy(), eps.numpy(), t.numpy(), lab.numpy(), np.array(loss)
+    _params_sample(m, out)
+    np.savez(os.path.join(HERE, "ref_checkpoint", "expected.npz"), **out)
+    print("checkpoint case: resumed-step loss", loss)
+
+
 if __name__ == "__main__":
-    for name, (cfg, N, H, W, gain) in MODEL_CASES.items():
-        model_case(name, cfg, N, H, W, gain)
-    block_cases()
-    schedule_and_sampler_cases()
-    train_case()
-    sr_case()
+    which = sys.argv[1:]
+    if not which:
+        for name, (cfg, N, H, W, gain) in MODEL_CASES.items():
+            model_case(name, cfg, N, H, W, gain)
+        block_cases()
+        schedule_and_sampler_cases()
+        train_case()
+        sr_case()
+    if not which or "cold_doodle" in which:
+        cold_and_doodle_cases()
+    if not which or "checkpoint" in which:
+        checkpoint_case()

@@ -121,3 +121,54 @@ def test_data_parallel_training_command_line(tmp_path):
     assert "Steps: 2 / 2" in r.stderr                   # 16 images / (4 per rank x 2 ranks) = 2 steps per epoch
     ck = out / "checkpoint"
     assert (ck / "diffusion_2.pt").exists()
+
+
+def _base_cfg(out, **over):
+    cfg = dict(checkpoint_steps=100, lr_steps=1000, max_epoch=1, plot_img_count=2, use_conditional=False, flip_imgs=False,
+               dataset_path="synthetic:8:3:16:16", out_dir=str(out), model_checkpoint=None, config_checkpoint=None,
+               load_diffusion_optim=False, diffusion_lr=2e-4, batch_size=4, noise_scheduler="COSINE",
+               min_noise_step=1, max_noise_step=1000, max_actual_noise_step=1000, skip_step=250, in_channel=3, out_channel=3,
+               num_layers=2, num_resnet_block=1, attn_layers=[1], attn_heads=1, attn_dim_per_head=None, time_dim=32,
+               cond_dim=None, min_channel=32, max_channel=64, img_recon=False, seed=3)
+    cfg.update(over)
+    return cfg
+
+
+def test_cold_and_doodle_training_command_lines(tmp_path):
+    """train_noise_cold_diffusion.py (x0 target, cold sampler at the checkpoint plot, no diffusion_alg key) then
+    generate_images_cold_diffusion.py; train_doodle_diffusion.py (image pairs, label-image plot, cond_img sampling) with
+    the bf16 training path switched on through the config."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, PYTHONPATH=PKG)
+    out = tmp_path / "cold"
+    cfg_path = tmp_path / "cold.json"
+    cfg_path.write_text(json.dumps(_base_cfg(out, img_recon=True, use_conditional=True, cond_dim=3)))
+    r = subprocess.run([sys.executable, os.path.join(PKG, "train_noise_cold_diffusion.py"), "-c", str(cfg_path), "--device", "cuda"],
+                       cwd=PKG, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ck = out / "checkpoint"
+    assert (ck / "diffusion_2.pt").exists() and (out / "plots" / "diffusion_plot_0.jpg").exists()
+    assert (out / "Noise-Cold-Diffusion.log").exists()
+    md = dict(model_name="diffusion_2.pt", img_C=3, img_H=16, img_W=16, in_channel=3, out_channel=3, num_layers=2,
+              num_resnet_block=1, attn_layers=[1], attn_heads=1, attn_dim_per_head=None, time_dim=32, cond_dim=3,
+              min_channel=32, max_channel=64, image_recon=True, max_noise=1000, min_noise=1, noise_scheduler="COSINE")
+    (ck / "config.json").write_text(json.dumps({"models": [md]}))
+    dest = tmp_path / "gen"
+    dest.mkdir()
+    r = subprocess.run([sys.executable, os.path.join(PKG, "generate_images_cold_diffusion.py"), "-c", str(ck / "config.json"),
+                        "--device", "cuda", "-s", "7", "-n", "2", "-d", str(dest), "--cold_step_size", "250", "-l", "0", "1", "0"],
+                       cwd=PKG, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(list((dest / "plots").glob("*.jpg"))) == 1
+
+    out = tmp_path / "doodle"
+    cfg = _base_cfg(out, dataset_path="synthetic-pairs:8:3:16:16", in_channel=6, diffusion_alg="DDIM", train_dtype="bf16")
+    del cfg["use_conditional"], cfg["flip_imgs"]          # train_doodle_diffusion.py has neither key
+    cfg_path = tmp_path / "doodle.json"
+    cfg_path.write_text(json.dumps(cfg))
+    r = subprocess.run([sys.executable, os.path.join(PKG, "train_doodle_diffusion.py"), "-c", str(cfg_path), "--device", "cuda"],
+                       cwd=PKG, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert (out / "checkpoint" / "diffusion_2.pt").exists() and (out / "plots" / "label_plot.jpg").exists()
+    assert (out / "plots" / "diffusion_plot_0.jpg").exists() and (out / "Doodle-Diffusion.log").exists()

@@ -1,0 +1,134 @@
+"""SURVEY §8(f) ranks 3-4 on the GPU: cold-diffusion (x0 target) and doodle (image-conditioned) training objectives
+against 2-step Adam goldens from the real reference, the doodle sampler call, and a checkpoint / config.json written by
+the real reference loaded strictly, resumed and sampled from."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import unet_oracle
+    return unet_oracle
+
+
+def _net(O, cfg):
+    from models.U_Net import U_Net
+    cfg = O.full_cfg(cfg)
+    net = U_Net(**cfg)
+    net.load_state_dict(O.seeded_params(cfg, seed=3, gain=1.8), strict=True)
+    return net.cuda()
+
+
+def _check_params(net, g, prefix):
+    bad = []
+    for k, v in net.state_dict().items():
+        got = v.detach().double().cpu().contiguous().flatten()[T(g[f"{prefix}pidx/{k}"])]
+        ref = T(g[f"{prefix}pval/{k}"]).double()
+        if not torch.allclose(got, ref, rtol=1e-3, atol=5e-5):
+            bad.append((k, float((got - ref).abs().max())))
+    assert not bad, bad[:8]
+
+
+def test_cold_diffusion_training_steps_golden(dev, O):
+    """train_noise_cold_diffusion.py:307-348: x0_hat = U_Net(q(x_t|x_0), t, labels) with a Tanh head, MSE against x_0."""
+    import degraders as D
+    from sdm_hip.trainer import DiffusionTrainer
+    g = np.load(os.path.join(GOLDEN, "cold_doodle.npz"))
+    net = _net(O, json.loads(str(g["cold/cfg"])))
+    tr = DiffusionTrainer(net, D.CosineNoiseDegradation(1000), lr=2e-3, objective="x0")
+    for i in range(2):
+        loss = tr.step(T(g[f"cold/x0_{i}"]).cuda(), T(g[f"cold/lab_{i}"]).cuda(), eps=T(g[f"cold/eps_{i}"]).cuda(),
+                       t=T(g[f"cold/t_{i}"]).cuda())
+        assert abs(float(loss) - float(g["cold/losses"][i])) < 5e-5, (i, float(loss), float(g["cold/losses"][i]))
+    _check_params(net, g, "cold/")
+    with pytest.raises(ValueError):
+        DiffusionTrainer(net, D.CosineNoiseDegradation(1000), objective="v")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_doodle_training_and_sampling_golden(dev, O, use_graph):
+    """train_doodle_diffusion.py:283-320 (cat((x_t, lbl_data), 1), noise target) and :398-410 (DDIM with the label image as
+    cond_img)."""
+    import degraders as D
+    import diffusion_sampling_algorithms as S
+    from sdm_hip.trainer import DiffusionTrainer
+    g = np.load(os.path.join(GOLDEN, "cold_doodle.npz"))
+    net = _net(O, json.loads(str(g["doodle/cfg"])))
+    sched = D.CosineNoiseDegradation(1000)
+    out = S.ddim_sampling(net, sched, T(g["doodle/samp_xT"]).cuda(), 1, 1000, T(g["doodle/samp_lbl"]).cuda(), None, 250, "cuda",
+                          lambda *a, **k: None, use_graph=use_graph)
+    assert rel(out, T(g["doodle/samp_out"])) < 2e-5
+    tr = DiffusionTrainer(net, sched, lr=2e-3)
+    for i in range(2):
+        loss = tr.step(T(g[f"doodle/x0_{i}"]).cuda(), None, eps=T(g[f"doodle/eps_{i}"]).cuda(), t=T(g[f"doodle/t_{i}"]).cuda(),
+                       cond_img=T(g[f"doodle/lbl_{i}"]).cuda())
+        assert abs(float(loss) - float(g["doodle/losses"][i])) < 5e-5, (i, float(loss), float(g["doodle/losses"][i]))
+    _check_params(net, g, "doodle/")
+
+
+def test_reference_checkpoint_resume_and_generate(dev, O, tmp_path):
+    """A checkpoint written by the real reference (tests/golden/ref_checkpoint/): strict load of the model, Adam state into
+    the fused optimizer, forward == the reference's forward, ONE resumed step == the reference's resumed step, and both
+    generators run from the export_models.py-shaped config.json."""
+    import degraders as D
+    from generate_images_cold_diffusion import generate_images_cold_diffusion
+    from generate_images_diffusion import _UNET_KEYS, generate_images_diffusion
+    from models.U_Net import U_Net
+    from sdm_hip.trainer import DiffusionTrainer
+    from utils.utils import load_checkpoint
+    d = os.path.join(GOLDEN, "ref_checkpoint")
+    ok, ck = load_checkpoint(os.path.join(d, "diffusion_1.pt"), log=lambda *a: None)
+    assert ok
+    with open(os.path.join(d, "config.json")) as f:
+        md = json.load(f)["models"][0]
+    net = U_Net(**{k: md[v] for k, v in _UNET_KEYS.items()})
+    net.load_state_dict(ck["model"], strict=True)
+    net = net.cuda()
+    e = np.load(os.path.join(d, "expected.npz"))
+    net.eval()
+    with torch.no_grad():
+        y = net(T(e["fwd_x"]).cuda(), T(e["fwd_t"]).cuda(), T(e["fwd_lab"]).cuda())
+    assert rel(y, T(e["fwd_y"])) < 2e-5
+    tr = DiffusionTrainer(net, D.CosineNoiseDegradation(1000), lr=2e-3)
+    tr.opt.load_state_dict(ck["optimizer"])
+    assert tr.opt.step_count == 1
+    loss = tr.step(T(e["x0"]).cuda(), T(e["lab"]).cuda(), eps=T(e["eps"]).cuda(), t=T(e["t"]).cuda())
+    assert abs(float(loss) - float(e["loss"])) < 5e-5
+    _check_params(net, e, "")
+    # the fused optimizer's state goes back out in torch.optim.Adam's layout
+    sd = tr.opt.state_dict()
+    assert set(sd["state"].keys()) == set(ck["optimizer"]["state"].keys())
+    assert all(float(v["step"]) == 2.0 for v in sd["state"].values())
+    # generators on the reference-shaped inference config
+    quiet = lambda *a, **k: None
+    args = ["-c", os.path.join(d, "config.json"), "--device", "cuda", "-n", "2", "-s", "1", "-l", "1", "0"]
+    imgs = generate_images_diffusion(args + ["--diff_alg", "ddim", "--ddim_step_size", "250"], log=quiet, save_locally=False)
+    assert imgs.shape == (2, 3, 8, 8) and bool(torch.isfinite(imgs).all())
+    imgs = generate_images_cold_diffusion(args + ["--cold_step_size", "250"], log=quiet, save_locally=False)
+    assert imgs.shape == (2, 3, 8, 8) and bool(torch.isfinite(imgs).all())
+    with pytest.raises(ValueError, match="labels"):
+        generate_images_cold_diffusion(args[:-3] + ["--cold_step_size", "250"], log=quiet, save_locally=False)

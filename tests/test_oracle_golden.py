@@ -178,3 +178,57 @@ def test_sr_path():
     for k, v in tr.P.items():
         got = v.detach().double().flatten()[T(g[f"pidx/{k}"])]
         assert torch.allclose(got, T(g[f"pval/{k}"]).double(), rtol=1e-3, atol=2e-5), k
+
+
+def test_cold_and_doodle_objectives():
+    """x0-target (cold diffusion) and image-conditioned (doodle) step bodies and the doodle DDIM run, against the reference
+    (train_noise_cold_diffusion.py:307-348, train_doodle_diffusion.py:283-320,398-410)."""
+    g = load("cold_doodle.npz")
+    cos = O.CosineSchedule(1000)
+    cfg = O.full_cfg(json.loads(str(g["cold/cfg"])))
+    tr = O.OracleTrainer(O.seeded_params(cfg, seed=3, gain=1.8), cfg, cos, lr=2e-3)
+    for i in range(2):
+        loss = tr.step(T(g[f"cold/x0_{i}"]), T(g[f"cold/t_{i}"]), T(g[f"cold/eps_{i}"]), T(g[f"cold/lab_{i}"]), target="x0")
+        assert abs(loss - float(g["cold/losses"][i])) < 2e-5
+    for k, v in tr.P.items():
+        got = v.detach().double().flatten()[T(g[f"cold/pidx/{k}"])]
+        assert torch.allclose(got, T(g[f"cold/pval/{k}"]).double(), rtol=1e-3, atol=2e-5), k
+    cfg = O.full_cfg(json.loads(str(g["doodle/cfg"])))
+    P = O.seeded_params(cfg, seed=3, gain=1.8)
+    out, _ = O.ddim_sample(P, cfg, cos, T(g["doodle/samp_xT"]), 1, 1000, 250, cond_img=T(g["doodle/samp_lbl"]))
+    assert torch.allclose(out, T(g["doodle/samp_out"]), rtol=1e-4, atol=1e-5)
+    tr = O.OracleTrainer(P, cfg, cos, lr=2e-3)
+    for i in range(2):
+        loss = tr.step(T(g[f"doodle/x0_{i}"]), T(g[f"doodle/t_{i}"]), T(g[f"doodle/eps_{i}"]), None,
+                       cond_img=T(g[f"doodle/lbl_{i}"]))
+        assert abs(loss - float(g["doodle/losses"][i])) < 2e-5
+    for k, v in tr.P.items():
+        got = v.detach().double().flatten()[T(g[f"doodle/pidx/{k}"])]
+        assert torch.allclose(got, T(g[f"doodle/pval/{k}"]).double(), rtol=1e-3, atol=2e-5), k
+
+
+def test_reference_written_checkpoint_loads_strictly():
+    """tests/golden/ref_checkpoint/: a checkpoint torch.save'd by the REAL reference (model + Adam state), its config
+    checkpoint and the export_models.py-shaped config.json.  Loaded with weights_only=True; the keys match the drop-in
+    U_Net strictly (dead parameters included) and the oracle reproduces the reference's forward from those weights."""
+    from models.U_Net import U_Net
+    from generate_images_diffusion import _UNET_KEYS
+    d = os.path.join(GOLDEN, "ref_checkpoint")
+    ck = torch.load(os.path.join(d, "diffusion_1.pt"), map_location="cpu", weights_only=True)
+    cc = torch.load(os.path.join(d, "config_1.pt"), map_location="cpu", weights_only=True)
+    assert set(ck) == {"model", "optimizer"} and cc == {"starting_epoch": 0, "global_steps": 1}
+    with open(os.path.join(d, "config.json")) as f:
+        md = json.load(f)["models"][0]
+    kw = {k: md[v] for k, v in _UNET_KEYS.items()}
+    net = U_Net(**kw)
+    net.load_state_dict(ck["model"], strict=True)
+    assert list(net.state_dict().keys()) == list(ck["model"].keys())
+    # optimizer state: one entry per LIVE parameter (the 40-odd dead ones never get a gradient), indexed like parameters()
+    live = {i for i, (n, _) in enumerate(net.named_parameters())
+            if ".adagn.y_shift." not in n and not (".attn_layers." in n and ".norm." in n)}
+    assert set(ck["optimizer"]["state"].keys()) == live
+    e = np.load(os.path.join(d, "expected.npz"))
+    cfg = O.full_cfg(kw)
+    with torch.no_grad():
+        y = O.unet_forward({k: v for k, v in ck["model"].items()}, cfg, T(e["fwd_x"]), T(e["fwd_t"]), T(e["fwd_lab"]))
+    assert torch.allclose(y, T(e["fwd_y"]), rtol=1e-4, atol=2e-6)
