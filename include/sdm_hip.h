@@ -297,6 +297,14 @@ int sdm_cold_update(float* x, const float* x0_hat, const float* noise, const flo
  * down-scaling is block averaging, integer up-scaling is pixel replication. */
 int sdm_area_resize(const float* x, float* out, int planes, int Hin, int Win, int Hout, int Wout, sdm_stream_t s);
 
+/* Input pipeline on the device (replaces cv2.imread + DataLoader workers + per-image hflip, train_diffusion.py:148-152,
+ * 312-314; img_dataset.py:26-36): the decoded dataset lives in HBM as uint8 [images][H][W][C] (BGR, as cv2 loads it);
+ * out[b][c][y][x] = lut256[cache[idx[b]][y][flip[b] ? W-1-x : x][c]] -- gather + normalise + horizontal flip + HWC->CHW in
+ * one pass.  lut256 is the host-computed table (v - 127.5) / 127.5 (float64 then rounded to float32, as the reference
+ * does per pixel); flip may be NULL. */
+int sdm_u8_gather_nchw(const uint8_t* cache_nhwc, const int64_t* idx, const uint8_t* flip, const float* lut256,
+                       float* out_nchw, int batch, int C, int H, int W, sdm_stream_t s);
+
 /* Step-table cursor for a hipGraph-captured sampling step: t_cur[0] = t_table[*cursor];
  * coef_cur[0..ncoef) = coef_table[*cursor][0..ncoef); ++*cursor (saturating at nsteps, reads clamp to the last row, so
  * *cursor - 1 is the index of the step in flight for all nsteps steps).  With it the captured

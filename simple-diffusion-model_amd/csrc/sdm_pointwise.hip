@@ -1185,3 +1185,39 @@ extern "C" int sdm_adam_multi(const sdm_adam_job* jobs_dev, int njobs, int64_t m
   SDM_CHECK_LAUNCH("adam_multi");
   return SDM_OK;
 }
+
+// --------------------------------------------------------------------------------------------
+// Input pipeline on the device (replaces cv2.imread + 4 DataLoader workers + the per-image Python
+// hflip of train_diffusion.py:148-152,312-314): the whole dataset sits in HBM as decoded uint8 HWC (BGR) images; a batch
+// is one gather that normalises through a 256-entry table ((v - 127.5) / 127.5, computed on the host exactly as the
+// reference does: float64, then rounded to float32), flips horizontally where asked and writes NCHW fp32.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void u8_gather_nchw_kernel(const uint8_t* __restrict__ cache, const int64_t* __restrict__ idx,
+                                                             const uint8_t* __restrict__ flip, const float* __restrict__ lut,
+                                                             float* __restrict__ out, int C, int H, int W, long long total) {
+  __shared__ float slut[256];
+  slut[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  const long long HW = (long long)H * W;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long b = e / (HW * C);
+    long long r = e - b * HW * C;
+    const int c = (int)(r / HW);
+    r -= (long long)c * HW;
+    const int y = (int)(r / W), x = (int)(r - (long long)y * W);
+    const int xs = (flip && flip[b]) ? W - 1 - x : x;
+    out[e] = slut[cache[((idx[b] * H + y) * W + xs) * C + c]];
+  }
+}
+
+extern "C" int sdm_u8_gather_nchw(const uint8_t* cache_nhwc, const int64_t* idx, const uint8_t* flip, const float* lut256,
+                                  float* out_nchw, int batch, int C, int H, int W, sdm_stream_t s) {
+  SDM_CHECK_ARG(cache_nhwc && idx && lut256 && out_nchw && batch > 0 && C > 0 && H > 0 && W > 0, "u8_gather_nchw: bad args");
+  const long long total = (long long)batch * C * H * W;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(u8_gather_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, cache_nhwc, idx, flip, lut256, out_nchw, C,
+                     H, W, total);
+  SDM_CHECK_LAUNCH("u8_gather_nchw");
+  return SDM_OK;
+}

@@ -12,10 +12,16 @@ import torch
 from torch.utils.data import Dataset
 
 
-def _load_bgr(path):
+def _load_bgr_u8(path):
+    """Decoded image as cv2.imread returns it: uint8 [H, W, 3], BGR."""
     from PIL import Image
-    rgb = np.asarray(Image.open(path).convert("RGB"), dtype=np.float32)
-    return torch.from_numpy(((rgb[:, :, ::-1] - 127.5) / 127.5).copy()).permute(2, 0, 1).contiguous()
+    return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)[:, :, ::-1])
+
+
+def _load_bgr(path):
+    """img_dataset.py:26-36: (img.astype(float) - 127.5) / 127.5 in float64, then .float(), then CHW."""
+    bgr = _load_bgr_u8(path)
+    return torch.from_numpy((bgr.astype(float) - 127.5) / 127.5).float().permute(2, 0, 1).contiguous()
 
 
 class SyntheticDataset(Dataset):
@@ -74,13 +80,14 @@ class ConditionalImgDataset(Dataset):
     def __len__(self):
         return len(self.dataset)
 
+    def _path(self, path):
+        return path if (os.path.isabs(path) or os.path.exists(path)) else os.path.join(self.root, path)
+
     def __getitem__(self, i):
         if len(self.dataset) <= 0:
             raise Exception("No data found in dataset.")
         path, labels = self.dataset[i]
-        if not os.path.isabs(path) and not os.path.exists(path):
-            path = os.path.join(self.root, path)
-        return _load_bgr(path), torch.Tensor(labels)
+        return _load_bgr(self._path(path)), torch.Tensor(labels)
 
 
 class DoodleImgDataset(Dataset):

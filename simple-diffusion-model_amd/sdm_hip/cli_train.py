@@ -143,6 +143,15 @@ def run_training(sr=False, mode=None):
                                sr=(cfg["lr_dim"], cfg["sr_dim"], cfg["cond_t"]) if sr else None,
                                objective="x0" if cold else "eps",
                                train_dtype=torch.bfloat16 if cfg.get("train_dtype") == "bf16" else None)
+    cached = False
+    if cfg.get("device_cache") and not doodle and not str(cfg["dataset_path"]).startswith("synthetic"):
+        # extension: the decoded dataset lives in HBM as uint8; batches are gathered / normalised / flipped by one kernel
+        from custom_dataset.device_cache import CachedLoader, DeviceImageCache
+        cache = DeviceImageCache(dataset, dev, log=logging.info)
+        loader = CachedLoader(cache, cfg["batch_size"], rank, world, flip=cfg["flip_imgs"], generator=trainer.gen,
+                              conditional=cfg["use_conditional"])
+        sampler, cached = loader if world > 1 else None, True
+        logging.info(f"device cache: {len(cache):,} images, {cache.images.numel() / 2**20:.1f} MiB of HBM")
     opt = trainer.opt
     if ckpt is not None and cfg["load_diffusion_optim"]:
         opt.load_state_dict(ckpt["optimizer"])
@@ -174,7 +183,7 @@ def run_training(sr=False, mode=None):
             else:
                 x0, labels = data.to(dev, non_blocking=True), None
             x0 = x0.float()
-            if cfg["flip_imgs"]:                   # per-image horizontal flip with p = 0.5 (:312-314)
+            if cfg["flip_imgs"] and not cached:    # per-image horizontal flip with p = 0.5 (:312-314)
                 flip = torch.rand(x0.shape[0], device=dev, generator=trainer.gen) < 0.5     # per-rank stream
                 x0 = torch.where(flip[:, None, None, None], x0.flip(-1), x0)
             loss = trainer.step(x0, labels, cond_img=cond_img)

@@ -119,6 +119,7 @@ _PROTOS = {
     "sdm_cold_update": (_i, [fp, fp, fp, fp, _sz, fp]),
     "sdm_area_resize": (_i, [fp, fp, _i, _i, _i, _i, _i, fp]),
     "sdm_step_advance": (_i, [fp, fp, fp, _i, _i, fp, fp, fp]),
+    "sdm_u8_gather_nchw": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "sdm_adam_multi": (_i, [fp, _i, _i64, _f, _f, _f, _f, _f, _f, _f, fp, fp]),
     # bf16 storage path (forward / sampling)
     "sdm_igemm_bf16": (_i, [C.POINTER(IgemmDesc), _i, fp]),

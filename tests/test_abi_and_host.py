@@ -197,3 +197,14 @@ def test_conditional_dataset_reads_the_reference_tinydb_schema(tmp_path):
     (tmp_path / "nolabels.json").write_text(json.dumps({"Data": db["Data"]}))
     with pytest.raises(Exception, match="No data found in Labels table"):
         ConditionalImgDataset(str(tmp_path / "nolabels.json"))
+
+
+def test_normalisation_table_matches_the_reference_arithmetic():
+    """img_dataset.py:29-32: (img.astype(float) - 127.5) / 127.5 in float64, then .float(): the 256-entry table the device
+    input pipeline gathers through holds exactly those values."""
+    import numpy as np
+    from custom_dataset.device_cache import norm_table
+    v = np.arange(256, dtype=np.uint8)
+    ref = torch.from_numpy((v.astype(float) - 127.5) / 127.5).float()
+    assert torch.equal(norm_table(), ref)
+    assert float(ref[0]) == -1.0 and float(ref[255]) == 1.0

@@ -172,3 +172,25 @@ def test_cold_and_doodle_training_command_lines(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     assert (out / "checkpoint" / "diffusion_2.pt").exists() and (out / "plots" / "label_plot.jpg").exists()
     assert (out / "plots" / "diffusion_plot_0.jpg").exists() and (out / "Doodle-Diffusion.log").exists()
+
+
+def test_training_from_image_files_through_the_device_cache(tmp_path):
+    """train_diffusion.py on real image files (glob dataset, flips on) with the extension key "device_cache": the decoded
+    uint8 dataset lives in HBM and batches come from the fused gather/normalise/flip kernel."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    (tmp_path / "imgs").mkdir()
+    for i in range(8):
+        Image.fromarray(rng.integers(0, 256, (16, 16, 3), dtype=np.uint8)).save(tmp_path / "imgs" / f"{i}.png")
+    out = tmp_path / "run"
+    cfg = _base_cfg(out, dataset_path=str(tmp_path / "imgs" / "*.png"), flip_imgs=True, diffusion_alg="DDIM", device_cache=True)
+    cfg_path = tmp_path / "train.json"
+    cfg_path.write_text(json.dumps(cfg))
+    r = subprocess.run([sys.executable, os.path.join(PKG, "train_diffusion.py"), "-c", str(cfg_path), "--device", "cuda"],
+                       cwd=PKG, env=dict(os.environ, PYTHONPATH=PKG), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "device cache: 8 images" in r.stderr and "Steps: 2 / 2" in r.stderr
+    assert (out / "checkpoint" / "diffusion_2.pt").exists()

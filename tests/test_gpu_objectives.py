@@ -132,3 +132,48 @@ def test_reference_checkpoint_resume_and_generate(dev, O, tmp_path):
     assert imgs.shape == (2, 3, 8, 8) and bool(torch.isfinite(imgs).all())
     with pytest.raises(ValueError, match="labels"):
         generate_images_cold_diffusion(args[:-3] + ["--cold_step_size", "250"], log=quiet, save_locally=False)
+
+
+def test_device_image_cache_matches_the_datasets_bit_for_bit(dev, tmp_path):
+    """the uint8 device cache + fused gather / normalise / flip kernel returns exactly the tensors the
+    reference-format datasets return (plain glob and TinyDB-conditional), flips == torch.flip on the width axis, and the
+    epoch loader shards like DistributedSampler (disjoint, rank-strided, same permutation on every rank)."""
+    from PIL import Image
+    from custom_dataset.device_cache import CachedLoader, DeviceImageCache
+    from custom_dataset.img_dataset import open_dataset
+    rng = np.random.default_rng(0)
+    recs = {}
+    for i in range(10):
+        Image.fromarray(rng.integers(0, 256, (12, 20, 3), dtype=np.uint8)).save(tmp_path / f"im{i:02d}.png")
+        recs[str(i + 1)] = {"filename": f"im{i:02d}.png", "a": float(i % 2), "b": float(i) / 10}
+    ds = open_dataset(str(tmp_path / "*.png"), False)
+    cache = DeviceImageCache(ds, dev)
+    assert len(cache) == 10 and cache.images.dtype == torch.uint8 and tuple(cache.images.shape) == (10, 12, 20, 3)
+    idx = torch.tensor([7, 0, 3, 3, 9], device=dev)
+    flip = torch.tensor([1, 0, 0, 1, 1], device=dev, dtype=torch.bool)
+    x, lab = cache.batch(idx, flip)
+    assert lab is None
+    want = torch.stack([ds[int(i)] for i in idx.cpu()])
+    want = torch.where(flip.cpu()[:, None, None, None], want.flip(-1), want)
+    assert torch.equal(x.cpu(), want)
+    x2, _ = cache.batch(idx)
+    assert torch.equal(x2.cpu(), torch.stack([ds[int(i)] for i in idx.cpu()]))
+    # conditional dataset (reference TinyDB schema)
+    (tmp_path / "db.json").write_text(json.dumps({"Data": recs, "Labels": {"1": {"labels": ["a", "b"]}}}))
+    dsc = open_dataset(str(tmp_path / "db.json"), True, 2)
+    cc = DeviceImageCache(dsc, dev)
+    xs, labs = cc.batch(torch.arange(10, device=dev))
+    for i in range(10):
+        img, lab = dsc[i]
+        assert torch.equal(xs[i].cpu(), img) and torch.equal(labs[i].cpu(), lab)
+    # loader: two ranks see disjoint halves of one permutation
+    seen = []
+    for r in range(2):
+        ld = CachedLoader(cc, 2, rank=r, world=2, flip=True, generator=torch.Generator(device=dev).manual_seed(r), conditional=True)
+        ld.set_epoch(3)
+        assert len(ld) == 2
+        got = [b for b in ld]
+        assert all(b[0].shape == (2, 3, 12, 20) and b[1].shape == (2, 2) for b in got)
+        seen.append(torch.cat([b[1][:, 1] for b in got]))
+    both = torch.cat(seen).cpu()
+    assert len(set((both * 10).round().int().tolist())) == 8          # 8 distinct images over the two ranks
