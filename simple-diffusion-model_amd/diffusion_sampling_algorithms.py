@@ -78,8 +78,9 @@ class _StepRunner:
             self.x.copy_(x0)
             self.cursor.zero_()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with ops.capture_scope() as kept, torch.cuda.graph(self.graph):
                 body()
+            self._kept = kept             # library buffers the graph points at live exactly as long as the graph
             self.x.copy_(x0)
             self.cursor.zero_()
             for i in range(self.nsteps):

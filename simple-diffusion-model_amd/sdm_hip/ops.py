@@ -137,14 +137,42 @@ class _SideStream:
 SIDE = _SideStream()
 
 
+class capture_scope:
+    """Lifetime of the library-owned buffers a captured hipGraph points at.
+
+    A captured graph bakes in the ADDRESSES of buffers that live outside its own memory pool: the zero-filled scratch
+    (_Workspace) and the y_scale job tables / output buffers (LinearBank).  Those caches are rebuilt when a shape key
+    changes; if the old set were simply dropped, a later replay would read freed -- and soon reused -- memory (the 06:18
+    fault of round 1: the training-step graph replayed after a checkpoint-plot forward with another embedding batch had
+    rebuilt the y_scale tables, and dereferenced a job table that the allocator had handed to someone else).  So whoever
+    captures a graph opens a scope; every cache that hands out a buffer during the capture registers it with keep(); the
+    scope's list is stored next to the graph and dies with it.  The caches themselves can then be bounded (LRU) without
+    ever freeing what a live graph still needs."""
+    _stack = []
+
+    def __enter__(self):
+        self.kept = []
+        capture_scope._stack.append(self.kept)
+        return self.kept
+
+    def __exit__(self, *exc):
+        capture_scope._stack.pop()
+        return False
+
+
+def keep(obj):
+    """Register ``obj`` with the graph capture in progress (no-op outside a capture_scope)."""
+    if capture_scope._stack and obj is not None:
+        capture_scope._stack[-1].append(obj)
+
+
 class _Workspace:
     """Zero-filled scratch (split-K partial sums, GroupNorm-backward channel sums), grown on demand; the kernels leave
-    what they touched zero-filled again.  Outgrown buffers are kept referenced: a captured hipGraph may
-    still hold their address."""
+    what they touched zero-filled again.  An outgrown buffer is dropped: a captured hipGraph that still points at it
+    holds its own reference (capture_scope)."""
 
     def __init__(self):
         self.buf = None
-        self.retired = []
 
     def get(self, nbytes, device):
         if nbytes == 0:
@@ -153,9 +181,8 @@ class _Workspace:
             if torch.cuda.is_current_stream_capturing():
                 raise lib.SdmError("zero-filled scratch (split-K / GroupNorm backward) must be sized by a warm-up call before "
                                    "graph capture")
-            if self.buf is not None:
-                self.retired.append(self.buf)
             self.buf = torch.zeros((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)   # zero-filled contract
+        keep(self.buf)
         return self.buf
 
 
@@ -867,9 +894,11 @@ class LinearBank:
     differentiated w.r.t. the shared embedding in ONE launch (sdm_linear_multi_bwd_dx).  Holds the device job
     tables; rebuilt when a parameter pointer or the embedding batch changes."""
 
+    MAX_SETS = 8                   # table sets kept (LRU); a live graph pins the set it captured through capture_scope
+
     def __init__(self):
         self.key = None
-        self.built = {}            # key -> table set; never replaced (captured graphs hold their addresses)
+        self.built = {}            # key -> table set, in least-recently-used order
 
     def _build(self, linears, M, dev):
         import ctypes
@@ -909,10 +938,14 @@ class LinearBank:
                 self._build(linears, M, emb.device)
                 self.built[key] = {k: getattr(self, k) for k in ("sizes", "out", "dout", "views", "dviews", "jobs", "bjobs",
                                                                  "chunk_job", "chunk_o0", "maxO")}
+                while len(self.built) > self.MAX_SETS:            # evict the least recently used set; a graph that
+                    self.built.pop(next(iter(self.built)))        # captured it keeps it alive until the graph is destroyed
             else:
+                self.built[key] = self.built.pop(key)             # most recently used last
                 for k, v in self.built[key].items():
                     setattr(self, k, v)
             self.key = key
+        keep(self.built[key])
         lib.call("sdm_linear_multi", _p(emb), emb.stride(0), M, K, _p(self.jobs), len(linears), self.maxO, _stream())
         if not private:
             return self.views

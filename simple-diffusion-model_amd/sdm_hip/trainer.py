@@ -235,9 +235,10 @@ class DiffusionTrainer:
                 v.copy_(bv)
             del backup
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with ops.capture_scope() as kept, torch.cuda.graph(self.graph):
                 self.g_loss = self._body(*self.g_in, hyper=self.hyper)
                 self.hyper[1:2].add_(1.0)
+            self._graph_kept = kept       # library buffers the graph points at live exactly as long as the graph
             self.g_key = key
             return self._replay(x0, labels, eps, t)
         return self._replay(x0, labels, eps, t)
