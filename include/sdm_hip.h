@@ -60,10 +60,10 @@ unsigned long long sdm_launch_count(void);
 
 /* Per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg; not capturable, so
  * keep it off inside hipGraph capture).  Classes: 0 igemm 128x128, 1 igemm 64x64, 2 igemm 32x128,
- * 3 wgrad 128x128, 4 wgrad 64x64, 5 igemm 128x64.  sdm_prof_begin(cap) arms it for up to cap launches; sdm_prof_end
+ * 3 wgrad 128x128, 4 wgrad 64x64, 5 igemm 128x64, 6 skinny-M weight streaming.  sdm_prof_begin(cap) arms it for up to cap launches; sdm_prof_end
  * synchronises the recorded events and fills, per class c: ms[c], launches[c], flops[c] (algorithmic 2*M*N*K*taps), bytes[c] (algorithmic: every
  * input row, weight and output element once, 4 B each). */
-#define SDM_PROF_CLASSES 6
+#define SDM_PROF_CLASSES 7
 int sdm_prof_begin(int capacity);
 int sdm_prof_end(double* ms, long long* launches, double* flops, double* bytes);
 

@@ -694,6 +694,188 @@ static int launch_igemm(const IgemmLaunch& L, int ntm, hipStream_t st) {
   return SDM_OK;
 }
 
+// --------------------------------------------------------------------------------------------
+// Skinny-M weight streaming (M <= 64 tile-grid rows: the 4x4 / 8x8 layers at small batch and the N=1 sampling step).
+// EXPERIMENT, off by default (see skinny_eligible): correct, but slower than the tiled kernels as measured.
+// There the contraction is a pure weight stream (9-38 MB per launch against <= 256 KB of activations; AI 8-32 FLOP/B,
+// SURVEY App. B), and the tiled kernels above are latency-bound on it: a workgroup keeps one or two 8 KB weight tiles in
+// flight, 4 MB chip-wide, which at ~1.5 us loaded HBM latency cannot exceed ~2-3 TB/s (measured 1.5 TB/s = 19 % of HBM).
+// Here NOTHING goes through LDS on the way in: a workgroup owns 32 output channels and one K-slice, its four waves split
+// that slice, and every lane streams its own weight row (the MFMA B operand: lane j,h <- W[n0+j][k+4h..k+4h+3], one 16-byte
+// load per 8 reduction steps) through a rotating queue of SK_D register slots -- 8 KB in flight per wave, 64 KB per CU.
+// The activation fragments (MFMA A operand, rows = the <= 64 pixels) come from L2 the same way, with the tap gather, the
+// concat split, the zero padding and a pending GroupNorm/AdaGN affine applied in registers.  The four partial 64x32
+// tiles meet in LDS and leave as coalesced fp32 atomics into the zero-filled split-K scratch; splitk_epilogue_kernel
+// finishes (bias, activation, residuals) exactly as for the tiled kernels.
+// --------------------------------------------------------------------------------------------
+#define SK_D 8   // weight fragments in flight per lane (x 16 B x 64 lanes = 8 KB per wave)
+
+template <int TMB, bool BKM, bool AFF>
+__global__ __launch_bounds__(256) void igemm_skinny_kernel(const IgemmLaunch L) {
+  const sdm_igemm_desc& d = L.d;
+  __shared__ long long s_aoff[SDM_MAX_TAPS * 64];     // source row of (tap, tile row) or -1 (padding / beyond M)
+  __shared__ long long s_orow[64];
+  __shared__ int s_img[64];
+  __shared__ int s_tapw[SDM_MAX_TAPS];                // weight slice of a tap (read in the load path: LDS, not the
+                                                      // kernel-argument segment, whose vector loads would drain the queue)
+  __shared__ float s_red[4][TMB * 32][33];
+  extern __shared__ __align__(16) float s_aff[];      // AFF: [2][images][K] scale | shift of the pending affine
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int tile_n = blockIdx.x / L.splitk, ks = blockIdx.x % L.splitk;
+  const int phase = blockIdx.y;
+  const int n0 = tile_n * 32;
+  const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
+  const float* a0 = d.a.p0 + b0 * d.a_bs0 + b1 * d.a_bs1;
+  const float* a1 = d.a.p1;
+  const float* bw = d.b + b0 * d.b_bs0 + b1 * d.b_bs1;
+  const int HtWt = d.Ht * d.Wt;
+  const int K = d.K, N = d.N, csplit = d.a.csplit;
+  const int ntap = d.ntaps[phase];
+  const int kch8 = K >> 3;                       // 8-deep reduction units per tap
+  const int U = ntap * kch8;
+  const int u0 = (int)((long long)U * ks / L.splitk), u1 = (int)((long long)U * (ks + 1) / L.splitk);
+  const int ub = u0 + (int)((long long)(u1 - u0) * wave / 4), ue = u0 + (int)((long long)(u1 - u0) * (wave + 1) / 4);
+
+  for (int e = tid; e < ntap * 64; e += 256) {
+    const int tp = e >> 6, m = e & 63;
+    long long off = -1;
+    if (m < d.M) {
+      const int n = m / HtWt, rem = m - n * HtWt;
+      const int y = rem / d.Wt, x = rem - y * d.Wt;
+      const int sy = y * d.sstride + d.tap_dy[phase][tp], sx = x * d.sstride + d.tap_dx[phase][tp];
+      if ((unsigned)sy < (unsigned)d.a.H && (unsigned)sx < (unsigned)d.a.W) off = ((long long)n * d.a.H + sy) * d.a.W + sx;
+    }
+    s_aoff[e] = off;
+  }
+  if (tid < 64) {
+    long long o = -1;
+    int img = 0;
+    if (tid < d.M) {
+      const int n = tid / HtWt, rem = tid - n * HtWt;
+      const int y = rem / d.Wt, x = rem - y * d.Wt;
+      const int oy = y * d.ostride + d.ph_oy[phase], ox = x * d.ostride + d.ph_ox[phase];
+      if (oy < d.Ho && ox < d.Wo) o = ((long long)n * d.Ho + oy) * d.Wo + ox;
+      img = n;
+    }
+    s_orow[tid] = o;
+    s_img[tid] = img;
+  }
+  if (tid < SDM_MAX_TAPS) s_tapw[tid] = d.tap_w[phase][tid];
+  const int images = d.M / HtWt;
+  if (AFF) {   // the tables are tiny (images x K): staged once, read at use time without touching the load queue
+    for (int e = tid * 4; e < images * d.K; e += 1024) {
+      const int n = e / d.K, c = e - n * d.K;
+      *(f32x4*)&s_aff[e] = *(const f32x4*)(d.a.scale + (long long)n * d.a.aff_nstride + c);
+      *(f32x4*)&s_aff[images * d.K + e] = *(const f32x4*)(d.a.shift + (long long)n * d.a.aff_nstride + c);
+    }
+  }
+  __syncthreads();
+
+  const bool nok = n0 + j < N;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // Branch-free load path (so that the compiler's counted s_waitcnt vmcnt(N) follows the static queue slots): the tap of
+  // a unit, its weight slice and its source rows are re-derived per unit with arithmetic and two LDS reads.
+  const int aimg0 = s_img[j], aimg1 = s_img[(TMB - 1) * 32 + j];
+  struct Frag { f32x4 w; f32x4 a[TMB]; int c; int ok; };      // ok: bit i = row block i reads a real (non-padding) row
+  auto load_unit = [&](Frag& f, int u) {      // issues the loads of reduction unit u (8 k-steps) for this lane
+    const int t = u / kch8, q = u - t * kch8;
+    const int c = q * 8 + 4 * h;
+    const float* bt = bw + (long long)s_tapw[t] * d.b_tap_stride;
+    if (!BKM) {
+      f.w = *(const f32x4*)(bt + (long long)(nok ? n0 + j : 0) * d.ldb + c);
+    } else {
+      const float* p = bt + (long long)c * d.ldb + (nok ? n0 + j : 0);
+      f.w.x = p[0];
+      f.w.y = p[d.ldb];
+      f.w.z = p[2 * d.ldb];
+      f.w.w = p[3 * d.ldb];
+    }
+    f.ok = 0;
+#pragma unroll
+    for (int i = 0; i < TMB; ++i) {
+      const long long ro = s_aoff[t * 64 + i * 32 + j];
+      const long long r = ro < 0 ? 0 : ro;
+      f.ok |= ro < 0 ? 0 : (1 << i);
+      const float* p = c < csplit ? a0 + r * d.a.ld0 + c : a1 + r * d.a.ld1 + (c - csplit);
+      f.a[i] = *(const f32x4*)p;
+    }
+    f.c = c;
+  };
+  f32x16 acc[TMB];
+#pragma unroll
+  for (int i = 0; i < TMB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  auto fma_unit = [&](const Frag& f) {
+    const f32x4 wv = nok ? f.w : zero4;
+#pragma unroll
+    for (int i = 0; i < TMB; ++i) {
+      f32x4 av = f.a[i];
+      if (AFF) {
+        const int img = i == 0 ? aimg0 : aimg1;
+        av = av * *(const f32x4*)&s_aff[img * d.K + f.c] + *(const f32x4*)&s_aff[(images + img) * d.K + f.c];
+      }
+      av = (f.ok >> i) & 1 ? av : zero4;         // padding stays exactly zero AFTER the affine
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wv[s], acc[i], 0, 0, 0);
+    }
+  };
+
+  // rotating queue: slot q holds unit (q + SK_D * round); a slot is refilled right after it has been consumed, so
+  // SK_D - 1 younger fragments stay in flight behind every use.  Loads are unconditional (indices clamp to the wave's
+  // last unit: a few redundant L2 hits at the tail); only the matrix instructions sit behind the uniform bound check.
+  Frag fq[SK_D];
+  const int cnt = ue - ub;
+  if (cnt > 0) {
+#pragma unroll
+    for (int q = 0; q < SK_D; ++q) load_unit(fq[q], ub + (q < cnt ? q : cnt - 1));
+    for (int base = 0; base < cnt; base += SK_D) {
+#pragma unroll
+      for (int q = 0; q < SK_D; ++q) {
+        const int u = base + q;
+        if (u < cnt) fma_unit(fq[q]);
+        const int nu = u + SK_D;
+        load_unit(fq[q], ub + (nu < cnt ? nu : cnt - 1));
+      }
+    }
+  }
+
+  // fold the four K-quarters and leave as coalesced atomics: lane = output channel, 2 rows per wave-instruction
+#pragma unroll
+  for (int i = 0; i < TMB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_red[wave][i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h][j] = acc[i][r];
+  __syncthreads();
+  const int n = tid & 31;
+  if (n0 + n < N) {
+    for (int m = tid >> 5; m < TMB * 32; m += 8) {
+      const long long orow = s_orow[m];
+      if (orow < 0) continue;
+      const float v = (s_red[0][m][n] + s_red[1][m][n]) + (s_red[2][m][n] + s_red[3][m][n]);
+      atomicAdd(&d.ws[((long long)blockIdx.z * L.out_rows + orow) * N + n0 + n], v);
+    }
+  }
+}
+
+template <int TMB, bool BKM, bool AFF>
+static int launch_skinny(const IgemmLaunch& L, hipStream_t st) {
+  dim3 grid(L.ntn * L.splitk, L.d.nphase, L.d.batch);
+  double taps = 0;
+  for (int p = 0; p < L.d.nphase; ++p) taps += L.d.ntaps[p];
+  {
+    const double images = (double)L.d.M / ((double)L.d.Ht * L.d.Wt);
+    const double in_b = images * L.d.a.H * L.d.a.W * L.d.K, w_b = (double)L.d.K * L.d.N * taps, out_b = images * L.d.Ho * L.d.Wo * L.d.N;
+    sdm_prof_shape(L.d.M, L.d.N, L.d.K, (int)taps, L.splitk, 4.0 * L.d.batch * (in_b + w_b + out_b));
+  }
+  sdm_prof_pre(st);
+  const size_t dyn = AFF ? (size_t)2 * (L.d.M / (L.d.Ht * L.d.Wt)) * L.d.K * sizeof(float) : 0;
+  hipLaunchKernelGGL((igemm_skinny_kernel<TMB, BKM, AFF>), grid, dim3(256), dyn, st, L);
+  sdm_prof_post(st, 6, 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
+  SDM_CHECK_LAUNCH("igemm_skinny");
+  return SDM_OK;
+}
+
 static int igemm_validate(const sdm_igemm_desc* d) {
   SDM_CHECK_ARG(d != nullptr, "igemm: null desc");
   SDM_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "igemm: bad M/N/K %d %d %d", d->M, d->N, d->K);
@@ -716,6 +898,41 @@ static int igemm_validate(const sdm_igemm_desc* d) {
   return SDM_OK;
 }
 
+// Skinny-M weight streaming applies to: one GEMM (no batch), M <= 64 tile-grid rows, 16-byte aligned operands, K a multiple
+// of 8, at least 1 MB of weights to stream (below that the tiled kernels' latency is the same and they need no scratch).
+#define SKINNY_AFF_LDS_MAX (48 * 1024)
+static bool skinny_eligible(const sdm_igemm_desc* d) {
+  // OPT-IN (SDM_IGEMM_SKINNY=1).  Measured on MI355X (profiles/r02_skinny_probe.txt): 35.0 us against the tiled kernel's
+  // 20.6 us on M=64, N=K=1024, 9 taps (37.7 MB of weights) -- one 32-byte piece of 32 different weight rows per
+  // wave-instruction reaches 1.1 TB/s where the LDS-DMA tiles (128 contiguous bytes of 8 rows per instruction) reach 1.8.
+  static const char* on = getenv("SDM_IGEMM_SKINNY");
+  if (!(on && on[0] == '1')) return false;
+  if (d->batch != 1 || d->M > 64 || d->K % 8 != 0) return false;
+  int taps = 0;
+  for (int p = 0; p < d->nphase; ++p) taps += d->ntaps[p];
+  if ((double)d->K * d->N * taps * 4.0 < 1048576.0) return false;
+  const bool vecA = aligned16(d->a.p0) && d->a.ld0 % 4 == 0 && (d->a.p1 == nullptr || (aligned16(d->a.p1) && d->a.ld1 % 4 == 0));
+  if (!vecA) return false;
+  if (!d->b_kmajor && !(aligned16(d->b) && d->ldb % 4 == 0 && d->b_tap_stride % 4 == 0)) return false;
+  if (d->a.scale != nullptr) {
+    if (d->b_kmajor) return false;
+    const long images = d->M / (d->Ht * d->Wt);
+    if ((size_t)2 * images * d->K * sizeof(float) > SKINNY_AFF_LDS_MAX) return false;
+  }
+  return true;
+}
+
+static int skinny_splitk(const sdm_igemm_desc* d) {
+  int maxtaps = 0;
+  for (int p = 0; p < d->nphase; ++p) maxtaps = d->ntaps[p] > maxtaps ? d->ntaps[p] : maxtaps;
+  const int U = maxtaps * (d->K / 8);                      // 8-deep reduction units per output tile
+  const long wgs = (long)cdiv(d->N, 32) * d->nphase;
+  int sk = (int)((512 + wgs - 1) / wgs);                  // ~2 workgroups per CU
+  if (sk > U / 32) sk = U / 32;                            // >= 8 units per wave: the load queue must fill
+  if (sk < 1) sk = 1;
+  return sk;
+}
+
 struct TileCfg { int bm, bn; };
 static const TileCfg kCfgs[4] = {{128, 128}, {64, 64}, {32, 128}, {128, 64}};
 
@@ -723,6 +940,12 @@ static const TileCfg kCfgs[4] = {{128, 128}, {64, 64}, {32, 128}, {128, 64}};
 // `ovh` issue/barrier cycles per K-step; co-resident workgroups share the matrix pipe but hide each other's
 // overhead.  Split-K adds an atomic pass over the output.
 static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* ws_need) {
+  if (skinny_eligible(d)) {     // cfg 4: weight streaming; always finishes through the zero-filled scratch
+    *cfg = 4;
+    *splitk = skinny_splitk(d);
+    *ws_need = (size_t)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo * d->batch * d->N * sizeof(float);
+    return;
+  }
   const long M = d->M, N = d->N;
   const long ph = (long)d->nphase * d->batch;
   int maxtaps = 0;
@@ -819,6 +1042,13 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
   int cfg;
   size_t need;
   igemm_plan(d, &cfg, &L.splitk, &need);
+  if (cfg == 4 && (d->ws == nullptr || d->ws_bytes < need)) {     // no scratch for the streaming kernel: tiled path
+    static const TileCfg fallback = {64, 64};
+    (void)fallback;
+    cfg = d->M <= 32 ? 2 : 1;
+    L.splitk = 1;
+    need = 0;
+  }
   if (L.splitk > 1 && (d->ws == nullptr || d->ws_bytes < need)) L.splitk = 1;  // no scratch: run unsplit
   L.kchunks = cdiv(d->K, BK);
   const bool vecA = aligned16(d->a.p0) && d->a.ld0 % 4 == 0 && d->a_bs0 % 4 == 0 && d->a_bs1 % 4 == 0 &&
@@ -827,15 +1057,16 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
   const bool vec = vecA && vecB && d->K % 4 == 0 && (!d->b_kmajor || d->N % 4 == 0);
   const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
   L.out_rows = out_rows;
-  const int ntm = cdiv(d->M, kCfgs[cfg].bm);
-  L.ntn = cdiv(d->N, kCfgs[cfg].bn);
-  {
+  const int tcfg = cfg == 4 ? 1 : cfg;              // (the streaming kernel has no tile table entry)
+  const int ntm = cdiv(d->M, kCfgs[tcfg].bm);
+  L.ntn = cdiv(d->N, kCfgs[tcfg].bn);
+  if (cfg != 4) {
     // per-XCD L2 fill of the two tile orders: an XCD's run of c tiles spans (mt x nt) tiles of A rows / B columns
     static const char* xo = getenv("SDM_IGEMM_XCD_ORDER");   // tuning override: "n" / "m"
     const long c = cdiv((long)ntm * L.ntn, 8);
     int taps_all = 0;                                        // phases sit in gridDim.y: same XCD as their tile
     for (int ph = 0; ph < d->nphase; ++ph) taps_all += d->ntaps[ph];
-    const double a_tile = (double)kCfgs[cfg].bm * d->K, b_tile = (double)kCfgs[cfg].bn * d->K * taps_all;
+    const double a_tile = (double)kCfgs[tcfg].bm * d->K, b_tile = (double)kCfgs[tcfg].bn * d->K * taps_all;
     const double nfast = (double)cdiv(c, L.ntn) * a_tile + (double)(c < L.ntn ? c : L.ntn) * b_tile;
     const double mfast = (double)(c < ntm ? c : ntm) * a_tile + (double)cdiv(c, ntm) * b_tile;
     L.mfast = mfast < nfast ? 1 : 0;
@@ -845,12 +1076,19 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
   }
   const bool km = d->b_kmajor != 0;
   const bool aff = d->a.scale != nullptr;
+  bool finish = L.splitk > 1;
+  if (cfg == 4) {
+    L.ntn = cdiv(d->N, 32);
+    finish = true;
+    if (d->M <= 32) rc = km ? launch_skinny<1, true, false>(L, st) : (aff ? launch_skinny<1, false, true>(L, st) : launch_skinny<1, false, false>(L, st));
+    else rc = km ? launch_skinny<2, true, false>(L, st) : (aff ? launch_skinny<2, false, true>(L, st) : launch_skinny<2, false, false>(L, st));
+  } else
   if (cfg == 0) rc = dispatch_igemm<128, 128, 2, 2>(L, ntm, km, vec, aff, st);
   else if (cfg == 1) rc = dispatch_igemm<64, 64, 2, 2>(L, ntm, km, vec, aff, st);
   else if (cfg == 2) rc = dispatch_igemm<32, 128, 1, 4>(L, ntm, km, vec, aff, st);
   else rc = dispatch_igemm<128, 64, 2, 2>(L, ntm, km, vec, aff, st);
   if (rc != SDM_OK) return rc;
-  if (L.splitk > 1) {
+  if (finish) {
     const long long total = (long long)out_rows * d->batch * d->N;
     int grid = (int)((total + 1023) / 1024);
     if (grid > 2048) grid = 2048;

@@ -177,7 +177,7 @@ def launch_count():
     return int(_lib.sdm_launch_count())
 
 
-PROF_CLASSES = ("igemm_128x128", "igemm_64x64", "igemm_32x128", "wgrad_128x128", "wgrad_64x64", "igemm_128x64")
+PROF_CLASSES = ("igemm_128x128", "igemm_64x64", "igemm_32x128", "wgrad_128x128", "wgrad_64x64", "igemm_128x64", "igemm_skinny")
 
 
 def prof_begin(capacity=100000):
@@ -185,9 +185,10 @@ def prof_begin(capacity=100000):
 
 
 def prof_end():
-    ms = (C.c_double * 6)()
-    n = (C.c_longlong * 6)()
-    fl = (C.c_double * 6)()
-    by = (C.c_double * 6)()
+    k = len(PROF_CLASSES)
+    ms = (C.c_double * k)()
+    n = (C.c_longlong * k)()
+    fl = (C.c_double * k)()
+    by = (C.c_double * k)()
     call("sdm_prof_end", ms, n, fl, by)
-    return {PROF_CLASSES[i]: dict(ms=ms[i], launches=n[i], flops=fl[i], bytes=by[i]) for i in range(6)}
+    return {PROF_CLASSES[i]: dict(ms=ms[i], launches=n[i], flops=fl[i], bytes=by[i]) for i in range(k)}

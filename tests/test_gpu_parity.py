@@ -71,6 +71,12 @@ CONV_CASES = [
     ("c3s2", 1, 64, 64, 7, 9),          # odd spatial dims
     ("ct4", 2, 64, 32, 3, 5),
     ("ct4", 1, 128, 64, 8, 8),
+    # skinny-M weight-streaming kernel (M <= 64 tile rows, >= 1 MB of weights): forward and K-major data gradient
+    ("c3s1", 4, 512, 512, 4, 4),        # M = 64: two row blocks
+    ("c3s1", 1, 512, 256, 4, 4),        # M = 16: half-empty row block, N != K
+    ("c3s2", 3, 256, 384, 8, 8),        # stride 2: forward M = 48; data gradient M = 48 per sub-pixel phase (1..4 taps)
+    ("ct4", 2, 512, 256, 4, 4),         # transposed conv: 4 phases of 4 taps forward, 16 taps backward
+    ("c3s1", 5, 256, 200, 3, 3),        # M = 45, N not a multiple of 32
 ]
 
 
@@ -136,6 +142,20 @@ def test_conv_concat_affine_and_residual_epilogue(dev, L):
     conv2 = conv2.to(dev)
     a2 = ops.Act(rows(x2), n, h, w, scale=sc.cuda(), shift=sh.cuda())
     out2 = ops.conv_fwd(a2, conv2.taps(), conv2.bias, "c3s1", ops.ACT_NONE)
+    assert rel(unrows(out2.t, n, h, w), y2) < 2e-5
+    # the same three on the skinny-M weight-streaming kernel (M = 32 rows, 2.4 / 1.2 MB of weights)
+    n, c1, c2, cout, h, w = 2, 256, 256, 128, 4, 4
+    conv = L.TapConv(c1 + c2, cout, "c3s1")
+    x1, x2 = torch.randn(n, c1, h, w, generator=g), torch.randn(n, c2, h, w, generator=g)
+    y = F.conv2d(torch.cat((x1, x2), 1), conv.weight.detach().contiguous(), conv.bias.detach(), padding=1)
+    conv = conv.to(dev)
+    out = ops.conv_fwd(ops.Act(rows(x1), n, h, w, t2=rows(x2)), conv.taps(), conv.bias, "c3s1", ops.ACT_NONE)
+    assert rel(unrows(out.t, n, h, w), y) < 2e-5
+    conv2 = L.TapConv(c2, 256, "c3s1")
+    sc, sh = torch.randn(n, c2, generator=g), torch.randn(n, c2, generator=g)
+    y2 = F.conv2d(x2 * sc[:, :, None, None] + sh[:, :, None, None], conv2.weight.detach().contiguous(), conv2.bias.detach(), padding=1)
+    conv2 = conv2.to(dev)
+    out2 = ops.conv_fwd(ops.Act(rows(x2), n, h, w, scale=sc.cuda(), shift=sh.cuda()), conv2.taps(), conv2.bias, "c3s1", ops.ACT_NONE)
     assert rel(unrows(out2.t, n, h, w), y2) < 2e-5
     # broadcast (batch-1) affine table
     a3 = ops.Act(rows(x2), n, h, w, scale=sc[:1].cuda().contiguous(), shift=sh[:1].cuda().contiguous())
@@ -811,3 +831,17 @@ def test_two_forwards_then_backward_accumulates(dev, O):
         if e > lim:
             bad.append((k, e))
     assert not bad, bad[:8]
+
+
+def test_skinny_weight_streaming_kernel_opt_in():
+    """The skinny-M weight-streaming kernel is an opt-in experiment (SDM_IGEMM_SKINNY=1; slower than the tiled kernels as
+    measured, profiles/r02_skinny_probe.txt).  It stays correct: the conv cases (forward, K-major data gradient, 4-phase
+    transposed conv, concat + pending affine) pass with it switched on.  The switch is read once per process -> subprocess."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, SDM_IGEMM_SKINNY="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "conv_fwd_dgrad_wgrad or concat_affine"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
