@@ -31,6 +31,7 @@ __device__ __forceinline__ void wait_vmcnt_wg() {
 struct WgradBfLaunch {
   sdm_wgrad_desc d;
   int splitk, ntn, atomic_out;
+  int rows_per_step;   // FASTP: image rows covered by one 64-pixel K-step (64 / Wk when Wk < 64, else 1)
 };
 
 #define BKP 64   // pixels per K-step
@@ -46,7 +47,14 @@ struct WgradBfLaunch {
 // Fragment of v_mfma_f32_32x32x16_bf16 (lane l: r=l&31, h=l>>5 holds k = 8h..8h+7 of channel r): two transposing reads;
 // in each, the 16-lane group (l>>4) covers pixel rows kb..kb+3 (kb = 16*kk + 8h + 4*rd) x channels c0+16*((l>>4)&1)..+15,
 // lane 4q+p of the group supplies the address of row kb+q, channels +4p..+4p+3, and receives channel (l&15)'s 4 rows.
-template <int BT, int NBUF>
+// FASTP (the host sets it when a 64-pixel K-step is a whole number of image rows or an aligned piece of one row, i.e.
+// Wk % 64 == 0, or 64 % Wk == 0 and Hk % (64 / Wk) == 0 -- every power-of-two feature map of >= 64 pixels): the position
+// of a K-step is then WAVE-UNIFORM scalar state (image, first row, first column) advanced with scalar adds, and a lane's
+// pixel inside the step is a lane CONSTANT; a DMA address is one 64-bit add and its padding test two compares.  The
+// general walk (per-lane pixel coordinates with carries, two 64-bit multiplies per row) costs ~16 vector instructions per
+// matrix instruction and made the kernel issue-bound (profiles/r02_wgrad_bf16_512_pmc.json, round 2 first cut: 45 % of
+// wave time issuing, matrix pipe 20 % busy).
+template <int BT, int NBUF, bool FASTP>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradBfLaunch L) {
   const sdm_wgrad_desc& d = L.d;
   constexpr int TM = BT / 64, TN = BT / 64;     // 32x32 MFMA tiles per wave (waves 2x2)
@@ -92,14 +100,42 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradBfLaunch L) 
   int pn[IT], py[IT], px[IT];
   const int adv_x = BKP % d.Wk, qw = BKP / d.Wk;
   const int adv_y = qw % d.Hk, adv_n = qw / d.Hk;
+  // FASTP state: uniform (un, uy, ux) = image / first row / first column of the next K-step to issue; lane constants:
+  // row and column of this lane's pixels inside a step, their tap-shifted source coordinates minus the uniform part,
+  // and their element offsets minus the uniform part
+  int un = 0, uy = 0, ux = 0;
+  int lgy[IT], lgx[IT], lxy[IT], lxx[IT];
+  long long lgo[IT], lxo[IT];
+  if (FASTP) {
+    const long long p0 = (long long)it0 * BKP;
+    un = (int)(p0 / HW);
+    const int rem = (int)(p0 - (long long)un * HW);
+    uy = rem / d.Wk;
+    ux = rem - uy * d.Wk;
 #pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    const long long p = (long long)it0 * BKP + drow + RPP * i;
-    const int n = (int)(p / HW), rem = (int)(p - (long long)n * HW);
-    pn[i] = n;
-    py[i] = rem / d.Wk;
-    px[i] = rem - py[i] * d.Wk;
+    for (int i = 0; i < IT; ++i) {
+      const int r = drow + RPP * i;
+      const int ly = L.rows_per_step > 1 ? r / d.Wk : 0, lx = L.rows_per_step > 1 ? r - ly * d.Wk : r;
+      lgy[i] = ly * d.g_stride + gdy;
+      lgx[i] = lx * d.g_stride + gdx;
+      lxy[i] = ly * d.x_stride + xdy;
+      lxx[i] = lx * d.x_stride + xdx;
+      lgo[i] = ((long long)lgy[i] * d.g.W + lgx[i]) * d.g.ld0 + cm;
+      lxo[i] = xsrc0 ? ((long long)lxy[i] * d.x.W + lxx[i]) * d.x.ld0 + cn
+                     : ((long long)lxy[i] * d.x.W + lxx[i]) * d.x.ld1 + (cn - d.x.csplit);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const long long p = (long long)it0 * BKP + drow + RPP * i;
+      const int n = (int)(p / HW), rem = (int)(p - (long long)n * HW);
+      pn[i] = n;
+      py[i] = rem / d.Wk;
+      px[i] = rem - py[i] * d.Wk;
+    }
   }
+  const bf16_t* xb = xsrc0 ? x0 : x1;
+  const long long xld = xsrc0 ? d.x.ld0 : d.x.ld1;
 
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -109,6 +145,30 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradBfLaunch L) 
       const int buf = (issued - it0) % NBUF;
       char* Ad = As + buf * TILEB + __builtin_amdgcn_readfirstlane(wave) * 1024;
       char* Bd = Bs + buf * TILEB + __builtin_amdgcn_readfirstlane(wave) * 1024;
+      if (FASTP) {
+        // uniform part of the source coordinates / offsets of this K-step (scalar registers)
+        const int sgy = uy * d.g_stride, sgx = ux * d.g_stride, sxy = uy * d.x_stride, sxx = ux * d.x_stride;
+        const long long sgo = (((long long)un * d.g.H + sgy) * d.g.W + sgx) * d.g.ld0;
+        const long long sxo = (((long long)un * d.x.H + sxy) * d.x.W + sxx) * xld;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+          const bool gu = gch && (unsigned)(sgy + lgy[i]) < (unsigned)d.g.H && (unsigned)(sgx + lgx[i]) < (unsigned)d.g.W;
+          const bool xu = xch && (unsigned)(sxy + lxy[i]) < (unsigned)d.x.H && (unsigned)(sxx + lxx[i]) < (unsigned)d.x.W;
+          const bf16_t* gq = gu ? g0 + (sgo + lgo[i]) : zero;
+          const bf16_t* xq = xu ? xb + (sxo + lxo[i]) : zero;
+          __builtin_amdgcn_global_load_lds((glb_ptr)gq, (lds_ptr)(Ad + i * RPP * ROWB), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((glb_ptr)xq, (lds_ptr)(Bd + i * RPP * ROWB), 16, 0, 0);
+        }
+        if (L.rows_per_step > 1) {
+          uy += L.rows_per_step;
+        } else {
+          ux += BKP;
+          if (ux >= d.Wk) { ux = 0; uy += 1; }
+        }
+        if (uy >= d.Hk) { uy = 0; un += 1; }
+        ++issued;
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
         const int n = pn[i], y = py[i], x = px[i];
@@ -223,13 +283,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradBfLaunch L) 
     }
 }
 
-template <int BT, int NBUF>
+template <int BT, int NBUF, bool FASTP>
 static int launch_wgrad_bf16(const WgradBfLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * NBUF * BKP * 2 * BT;
   dim3 grid(ntm * L.ntn * L.splitk, L.d.ntaps, L.d.batch);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_bf16_kernel<BT, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)wgrad_bf16_kernel<BT, NBUF, FASTP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
     attr_set = true;
   }
   {
@@ -239,7 +300,7 @@ static int launch_wgrad_bf16(const WgradBfLaunch& L, int ntm, hipStream_t st) {
                    L.d.batch * (2.0 * (g_b + x_b) + 4.0 * w_b));
   }
   sdm_prof_pre(st);
-  hipLaunchKernelGGL((wgrad_bf16_kernel<BT, NBUF>), grid, dim3(256), lds, st, L);
+  hipLaunchKernelGGL((wgrad_bf16_kernel<BT, NBUF, FASTP>), grid, dim3(256), lds, st, L);
   sdm_prof_post(st, BT == 128 ? 3 : 4, 2.0 * L.d.M * L.d.N * (double)L.d.images * L.d.Hk * L.d.Wk * L.d.ntaps * L.d.batch);
   SDM_CHECK_LAUNCH("wgrad_bf16");
   return SDM_OK;
@@ -309,13 +370,21 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
         SDM_CHECK_LAUNCH("zero_rows");
       }
   }
+  // structured pixel walk when a 64-pixel K-step is an aligned piece of one image row or a whole number of rows
+  static const char* nofast = getenv("SDM_WGRAD_BF16_FASTP");
+  bool fastp = !(nofast && nofast[0] == '0');
+  if (d->Wk % BKP == 0) L.rows_per_step = 1;
+  else if (BKP % d->Wk == 0 && d->Hk % (BKP / d->Wk) == 0) L.rows_per_step = BKP / d->Wk;
+  else { L.rows_per_step = 0; fastp = false; }
   const bool use128 = fbt == 128 ? true : (fbt == 64 ? false : big);
+  int ntm2 = ntm;
   if (use128 != big) {   // forced tile: recompute the tile counts
     const int b2 = use128 ? 128 : 64;
     L.ntn = cdiv(d->N, b2);
-    return use128 ? launch_wgrad_bf16<128, 2>(L, cdiv(d->M, b2), st) : launch_wgrad_bf16<64, 3>(L, cdiv(d->M, b2), st);
+    ntm2 = cdiv(d->M, b2);
   }
-  return big ? launch_wgrad_bf16<128, 2>(L, ntm, st) : launch_wgrad_bf16<64, 3>(L, ntm, st);
+  if (use128) return fastp ? launch_wgrad_bf16<128, 2, true>(L, ntm2, st) : launch_wgrad_bf16<128, 2, false>(L, ntm2, st);
+  return fastp ? launch_wgrad_bf16<64, 3, true>(L, ntm2, st) : launch_wgrad_bf16<64, 3, false>(L, ntm2, st);
 }
 
 // --------------------------------------------------------------------------------------------
