@@ -142,8 +142,14 @@ typedef struct sdm_igemm_desc {
                              CONTRACT: the caller hands it over zero-filled once; every call leaves the part it
                              touched zero-filled again (the finishing pass clears what it reads) */
   size_t ws_bytes;
+  int defer_epilogue;     /* 1: if the library splits K, it leaves the RAW sums in ws ([out row][N], alpha / bias / act not yet
+                             applied) and returns SDM_DEFERRED instead of running its finishing pass: the caller's next
+                             kernel finishes them (sdm_gn_apply_fused folds the finishing pass into the GroupNorm that
+                             follows every U-Net conv block).  Only for batch == 1, no residual / out_preact / dact_z.  When
+                             the library does not split K the call behaves as usual and returns SDM_OK. */
 } sdm_igemm_desc;
 
+#define SDM_DEFERRED 1
 int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream);
 /* scratch the library may want for this problem (0 if it will not split K) */
 size_t sdm_igemm_workspace_bytes(const sdm_igemm_desc* d);
@@ -205,6 +211,19 @@ int sdm_head_conv_wgrad(const float* x_nhwc, const float* g_nchw, float* dw_tap,
 int sdm_gn_affine(const float* y, int64_t ldy, int images, int HW, int C, int groups, float eps,
                   const float* gamma, const float* beta, const float* mod, int mod_nstride,
                   float* scale, float* shift, float* mean, float* rstd, sdm_stream_t s);
+
+/* UNet_ConvBlock tail in ONE pass per (image, group) (custom_layers.py:222-229 conv -> Swish -> AdaGN, :35-45, and the
+ * ResidualBlock add :284-286), for no-grad forwards:
+ *   y   = src                                   (src_raw == 0: the conv's finished output rows, pitch ld_src)
+ *       = act(alpha * src + bias[c])            (src_raw == 1: split-K raw sums left by sdm_igemm(defer_epilogue), [rows][C];
+ *                                                cleared to zero again, as the scratch contract demands)
+ *   out = s * GroupNorm(y; gamma, beta) + s + cat(x0, x1)        s = mod[n or 0][c] (1 when mod == NULL; then no "+ s")
+ * GroupNorm statistics with fp32 partials folded into fp64, like sdm_gn_affine.  Replaces three launches of the sampling
+ * step (split-K finishing pass, sdm_gn_affine, sdm_affine_residual) with one; x0 NULL = no residual. */
+int sdm_gn_apply_fused(const float* src, int64_t ld_src, int src_raw, float alpha, const float* bias, int act,
+                       int images, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
+                       const float* mod, int mod_nstride, const float* x0, int64_t ldx0, const float* x1, int64_t ldx1,
+                       int csplit, float* out, int64_t ldo, sdm_stream_t s);
 
 /* out[r][c] = scale[n][c]*y[r][c] + shift[n][c] + cat(x0,x1)[r][c]   (ResidualBlock tail, custom_layers.py:284-286);
  * x0 NULL = affine only (materialises a conv input whose GroupNorm+AdaGN affine is pending). */

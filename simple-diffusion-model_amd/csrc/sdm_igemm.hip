@@ -895,6 +895,8 @@ static int igemm_validate(const sdm_igemm_desc* d) {
                 "igemm: affine-on-load needs K %% 4 == 0 and aligned tables");
   SDM_CHECK_ARG(d->ostride >= 1 && d->sstride >= 1 && d->Ho > 0 && d->Wo > 0, "igemm: bad strides/output dims");
   SDM_CHECK_ARG(d->act >= 0 && d->act <= 2, "igemm: bad act");
+  SDM_CHECK_ARG(!d->defer_epilogue || (d->batch == 1 && !d->res && !d->res2 && !d->out_preact && !d->dact_z),
+                "igemm: a deferred epilogue carries only alpha / bias / activation (batch 1)");
   return SDM_OK;
 }
 
@@ -1014,6 +1016,14 @@ static int dispatch_igemm(const IgemmLaunch& L, int ntm, bool kmajor, bool vec, 
     if (BM * BN <= 64 * 128 && L.d.K % 64 == 0 && nblocks <= 512 && !(bk64 && bk64[0] == '0')) {
       IgemmLaunch L2 = L;
       L2.kchunks = cdiv(L.d.K, 64);
+      // At most one workgroup per CU in the grid (the N=1 sampling step, the 4x4 / 8x8 layers): the whole LDS is this
+      // workgroup's, so the ring goes 3-4 deep (up to 128 KB: two or three 64-deep tiles in flight).  Such launches are pure latency
+      // chains -- a K-step computes for ~0.45 us against ~1 us of weight-fetch latency -- and the deeper ring hides it.
+      static const char* deep = getenv("SDM_IGEMM_DEEP");
+      constexpr int DEEP = (BM + BN <= 128) ? 4 : 3;      // 64x64: 4 x 32 KB; 32x128: 3 x 40 KB (the CU has 160 KB)
+      if (nblocks <= 256 && !(deep && deep[0] == '0'))
+        return kmajor ? launch_igemm_glds<BM, BN, WM, WN, true, DEEP, 64>(L2, ntm, st)
+                      : launch_igemm_glds<BM, BN, WM, WN, false, DEEP, 64>(L2, ntm, st);
       return kmajor ? launch_igemm_glds<BM, BN, WM, WN, true, 2, 64>(L2, ntm, st)
                     : launch_igemm_glds<BM, BN, WM, WN, false, 2, 64>(L2, ntm, st);
     }
@@ -1088,6 +1098,7 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
   else if (cfg == 2) rc = dispatch_igemm<32, 128, 1, 4>(L, ntm, km, vec, aff, st);
   else rc = dispatch_igemm<128, 64, 2, 2>(L, ntm, km, vec, aff, st);
   if (rc != SDM_OK) return rc;
+  if (finish && d->defer_epilogue) return SDM_DEFERRED;     // raw sums stay in ws: the caller's next kernel finishes them
   if (finish) {
     const long long total = (long long)out_rows * d->batch * d->N;
     int grid = (int)((total + 1023) / 1024);

@@ -1221,3 +1221,117 @@ extern "C" int sdm_u8_gather_nchw(const uint8_t* cache_nhwc, const int64_t* idx,
   SDM_CHECK_LAUNCH("u8_gather_nchw");
   return SDM_OK;
 }
+
+// --------------------------------------------------------------------------------------------
+// Fused tail of a conv block for no-grad forwards: [split-K finishing pass] + GroupNorm statistics + AdaGN modulation +
+// affine apply + residual add, one workgroup per (image, group), two sweeps over that group's slice (the second one
+// served by L2).  At N=1 every kernel of the sampling step costs a fixed ~4.5 us of dependent-launch latency whatever it
+// does (profiles/r02_sample_n1_kernel_stats.csv): this replaces three such launches per conv block by one.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 gnf_value(const float* __restrict__ p, int raw, float alpha, const f32x4 b, int act) {
+  f32x4 v = *(const f32x4*)p;
+  if (raw) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = sdm_act(v[i] * alpha + b[i], act);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(1024) void gn_apply_fused_kernel(float* __restrict__ src, long long lds_, int raw, float alpha,
+                                                              const float* __restrict__ bias, int act, int HW, int C,
+                                                              int groups, float eps, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ mod,
+                                                              int mod_ns, const float* __restrict__ x0, long long ldx0,
+                                                              const float* __restrict__ x1, long long ldx1, int csplit,
+                                                              float* __restrict__ out, long long ldo) {
+  __shared__ double red[2][16];
+  __shared__ float s_stat[2];
+  const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cpg = C / groups, q4 = cpg >> 2;
+  float* base = src + (long long)n * HW * lds_ + g * cpg;
+  const long long tot4 = (long long)HW * q4;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  double s1 = 0.0, s2 = 0.0;
+  for (long long e0 = threadIdx.x; e0 < tot4; e0 += 1024 * 8) {
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long e = e0 + (long long)u * 1024;
+      if (e < tot4) {
+        const long long pix = e / q4;
+        const int c = (int)(e - pix * q4) * 4;
+        const f32x4 b = (raw && bias) ? *(const f32x4*)(bias + g * cpg + c) : zero4;
+        const f32x4 v = gnf_value(base + pix * lds_ + c, raw, alpha, b, act);
+        p1 += (v.x + v.y) + (v.z + v.w);
+        p2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    }
+    s1 += p1;
+    s2 += p2;
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { a += red[0][w]; b += red[1][w]; }
+    const double total = (double)HW * cpg;
+    const double mean = a / total;
+    double var = b / total - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_stat[0] = (float)mean;
+    s_stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const float mu = s_stat[0], rstd = s_stat[1];
+  for (long long e = threadIdx.x; e < tot4; e += 1024) {
+    const long long pix = e / q4;
+    const int c = (int)(e - pix * q4) * 4;
+    const int ch = g * cpg + c;
+    float* sp = base + pix * lds_ + c;
+    const f32x4 b = (raw && bias) ? *(const f32x4*)(bias + ch) : zero4;
+    f32x4 v = gnf_value(sp, raw, alpha, b, act);
+    if (raw) *(f32x4*)sp = zero4;                       // the split-K scratch goes back zero-filled
+    const f32x4 ga = *(const f32x4*)(gamma + ch), be = *(const f32x4*)(beta + ch);
+    f32x4 o;
+    if (mod) {
+      const f32x4 sm = *(const f32x4*)(mod + (long long)n * mod_ns + ch);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {       // the same two-step form as sdm_gn_affine + sdm_affine_residual: scale*v + shift
+        const float sc = rstd * ga[i] * sm[i];
+        const float sh = (be[i] - mu * rstd * ga[i]) * sm[i] + sm[i];
+        o[i] = v[i] * sc + sh;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = v[i] * (rstd * ga[i]) + (be[i] - mu * rstd * ga[i]);
+    }
+    const long long row = (long long)n * HW + pix;
+    if (x0) o += (ch < csplit) ? *(const f32x4*)(x0 + row * ldx0 + ch) : *(const f32x4*)(x1 + row * ldx1 + (ch - csplit));
+    *(f32x4*)(out + row * ldo + ch) = o;
+  }
+}
+
+extern "C" int sdm_gn_apply_fused(const float* src, int64_t ld_src, int src_raw, float alpha, const float* bias, int act,
+                                  int images, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
+                                  const float* mod, int mod_nstride, const float* x0, int64_t ldx0, const float* x1,
+                                  int64_t ldx1, int csplit, float* out, int64_t ldo, sdm_stream_t s) {
+  SDM_CHECK_ARG(src && gamma && beta && out && images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_apply_fused: bad args");
+  SDM_CHECK_ARG(x0 == nullptr || x1 != nullptr || csplit >= C, "gn_apply_fused: csplit < C without second source");
+  const int cpg = C / groups;
+  SDM_CHECK_ARG(cpg % 4 == 0 && ld_src % 4 == 0 && ldo % 4 == 0 && aligned16(src) && aligned16(out) && aligned16(gamma) &&
+                    aligned16(beta) && (mod == nullptr || (aligned16(mod) && mod_nstride % 4 == 0)) &&
+                    (bias == nullptr || aligned16(bias)) &&
+                    (x0 == nullptr || (aligned16(x0) && ldx0 % 4 == 0 && csplit % 4 == 0)) &&
+                    (x1 == nullptr || (aligned16(x1) && ldx1 % 4 == 0)),
+                "gn_apply_fused: needs channels-per-group %% 4 == 0 and 16-byte aligned rows / tables");
+  SDM_CHECK_ARG(act >= 0 && act <= 2, "gn_apply_fused: bad act");
+  hipLaunchKernelGGL(gn_apply_fused_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, (float*)src, (long long)ld_src,
+                     src_raw, alpha, bias, act, HW, C, groups, eps, gamma, beta, mod, mod_nstride, x0, (long long)ldx0, x1,
+                     (long long)ldx1, csplit, out, (long long)ldo);
+  SDM_CHECK_LAUNCH("gn_apply_fused");
+  return SDM_OK;
+}

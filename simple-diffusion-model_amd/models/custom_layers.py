@@ -53,6 +53,7 @@ class RunCtx:
 
 
 MATERIALIZE_TRAIN = [os.environ.get("SDM_TRAIN_MATERIALIZE", "1") != "0"]
+FUSE_GN = [os.environ.get("SDM_FUSE_GN", "1") != "0"]       # fused conv-block tail in no-grad fp32 forwards
 
 
 def bf16_weight(mod, key, src_fn, transposed=False, pad_to=1):
@@ -432,6 +433,15 @@ class UNet_ConvBlock(nn.Module):
             ctx.rec[self] = (x, y, mod, mean, rstd)
         return y, (scale, shift)
 
+    def run_fused(self, ctx, x, emb, residual=None):
+        """conv -> SiLU -> AdaGN (+ residual) with the tail in one launch (sdm_gn_apply_fused); no-grad fp32 forwards."""
+        c = self.conv_layer.conv
+        act = ACT_SILU if self.use_activation else ACT_NONE
+        mod = ctx.mods[self.adagn] if ctx.mods is not None else self.adagn.modulation(emb)
+        y = ops.conv_fwd(x, c.taps(), c.bias, "c3s1", act, defer=True)     # nothing may touch the scratch until it is consumed
+        gn = self.adagn.group_norm
+        return ops.gn_apply_fused(y, gn.weight, gn.bias, mod, gn.groups, residual=residual)
+
     def backward(self, ctx, g, grads, res=None, res2=None):
         """g: gradient w.r.t. this block's output -- the modulated tensor when AdaGN is present, else the conv's
         pre-activation gradient (dz)."""
@@ -456,7 +466,21 @@ class ResidualBlock(nn.Module):
             raise NotImplementedError("1x1 shortcut is never instantiated by any U_Net (custom_layers.py:307-316)")
         self.shortcut = nn.Identity()
 
+    def _fusable(self, ctx, emb):
+        """No-grad fp32 forward with AdaGN on both conv blocks and GroupNorm groups of a multiple of 4 channels: the tail
+        of each conv block (split-K finishing pass, GroupNorm fold, affine, residual add) runs as ONE launch."""
+        if ctx.train or ctx.bf16 or emb is None or not FUSE_GN[0]:
+            return False
+        a1, a2 = getattr(self.conv_block_1, "adagn", None), getattr(self.conv_block_2, "adagn", None)
+        if a1 is None or a2 is None:
+            return False
+        c = self.conv_block_1.conv_layer.conv.cout
+        return c % (4 * a1.group_norm.groups) == 0 and c % (4 * a2.group_norm.groups) == 0
+
     def run(self, ctx, x, emb=None):
+        if self._fusable(ctx, emb):
+            x2 = self.conv_block_1.run_fused(ctx, x, emb)
+            return self.conv_block_2.run_fused(ctx, x2, emb, residual=x)
         y1, aff1 = self.conv_block_1.run(ctx, x, emb)
         if (ctx.bf16 or (ctx.train and MATERIALIZE_TRAIN[0])) and aff1 is not None:
             # the affine is materialised: the LDS-DMA tiles cannot apply it on the fly.  bf16 rows always; in training

@@ -38,7 +38,7 @@ class IgemmDesc(C.Structure):
         ("res", fp), ("ldres", C.c_int64), ("r_bs0", C.c_int64), ("r_bs1", C.c_int64),
         ("res2", fp), ("ldres2", C.c_int64),
         ("dact_z", fp), ("ldz", C.c_int64), ("dact_ncols", C.c_int),
-        ("ws", fp), ("ws_bytes", C.c_size_t),
+        ("ws", fp), ("ws_bytes", C.c_size_t), ("defer_epilogue", C.c_int),
     ]
 
 
@@ -96,6 +96,7 @@ _PROTOS = {
     "sdm_stem_conv_wgrad": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "sdm_head_conv_wgrad": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "sdm_gn_affine": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, fp, fp, fp, fp]),
+    "sdm_gn_apply_fused": (_i, [fp, _i64, _i, _f, fp, _i, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, fp]),
     "sdm_affine_residual": (_i, [fp, _i64, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, _i, _i, _i, fp]),
     "sdm_gn_adagn_bwd": (_i, [fp, _i64, fp, _i64, fp, _i64, _i, _i, _i, _i, fp, fp, fp, _i, fp, fp, fp, _i64,
                               fp, fp, fp, fp, fp, fp]),
@@ -159,10 +160,14 @@ def last_error():
     return _lib.sdm_last_error().decode()
 
 
+DEFERRED = 1      # sdm_igemm(defer_epilogue=1) left raw split-K sums for the caller's next kernel to finish
+
+
 def call(name, *args):
     rc = getattr(_lib, name)(*args)
-    if rc != 0:
+    if rc < 0:
         raise SdmError(f"{name} failed (rc={rc}): {last_error()}")
+    return rc
 
 
 def raw(name):

@@ -228,15 +228,25 @@ WEIGHT_EPOCH = [0]      # bumped whenever weights are rewritten behind torch's b
 
 
 def _launch_igemm(d, device, bf16=False, out_f32=False):
-    """bf16=True: operands (and the output unless out_f32) are bf16, see sdm_igemm_bf16 (forward / sampling path)."""
+    """bf16=True: operands (and the output unless out_f32) are bf16, see sdm_igemm_bf16 (forward / sampling path).
+    Returns the library's code: lib.DEFERRED when d.defer_epilogue was set and raw split-K sums were left in WS."""
     need = lib.raw("sdm_igemm_bf16_workspace_bytes" if bf16 else "sdm_igemm_workspace_bytes")(C.byref(d))
     ws = WS.get(need, device)
     d.ws = _p(ws)
     d.ws_bytes = ws.numel() * 4 if ws is not None else 0
     if bf16:
-        lib.call("sdm_igemm_bf16", C.byref(d), int(out_f32), _stream())
-    else:
-        lib.call("sdm_igemm", C.byref(d), _stream())
+        return lib.call("sdm_igemm_bf16", C.byref(d), int(out_f32), _stream())
+    return lib.call("sdm_igemm", C.byref(d), _stream())
+
+
+class Deferred:
+    """A conv output whose split-K finishing pass has NOT run: raw sums [rows, c] in the shared zero-filled scratch
+    (WS.buf), plus what the finishing pass would have applied.  Consumed -- and the scratch cleared -- by the very next
+    launch (gn_apply_fused); nothing else may touch WS in between."""
+    __slots__ = ("ws", "n", "h", "w", "c", "bias", "act")
+
+    def __init__(self, ws, n, h, w, c, bias, act):
+        self.ws, self.n, self.h, self.w, self.c, self.bias, self.act = ws, n, h, w, c, bias, act
 
 
 def to_bf16(t, out=None):
@@ -291,8 +301,9 @@ def conv_out_hw(h, w, kind):
     raise ValueError(kind)
 
 
-def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False):
-    """x: Act; wt: [taps, c_out, c_in] contiguous view; returns Act (plain)."""
+def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False, defer=False):
+    """x: Act; wt: [taps, c_out, c_in] contiguous view; returns Act (plain).  ``defer`` (fp32, no save_z): if the library
+    splits K it skips its finishing pass and a Deferred is returned instead (see gn_apply_fused)."""
     T, cout, cin = wt.shape
     assert cin == x.c, (cin, x.c)
     ho, wo = conv_out_hw(x.h, x.w, kind)
@@ -320,7 +331,9 @@ def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False):
     d.Ho, d.Wo = ho, wo
     d.out, d.ldo = _p(out), out.stride(0)
     d.bias, d.act, d.out_preact = _p(bias), act, _p(z)
-    _launch_igemm(d, wt.device, bf16=bf)
+    d.defer_epilogue = int(bool(defer) and not bf and not save_z)
+    if _launch_igemm(d, wt.device, bf16=bf) == lib.DEFERRED:
+        return Deferred(WS.buf, x.n, ho, wo, cout, bias, act)
     return Act(out, x.n, ho, wo, z=z)
 
 
@@ -738,6 +751,25 @@ def gn_affine(y, gamma, beta, mod, groups=32, eps=1e-5, want_stats=True):
     lib.call("sdm_gn_affine", _p(y.t), y.t.stride(0), y.n, y.h * y.w, C_, groups, eps, _p(gamma), _p(beta), _p(mod), mns,
              _p(scale), _p(shift), _p(mean), _p(rstd), _stream())
     return scale, shift, mean, rstd
+
+
+def gn_apply_fused(y, gamma, beta, mod, groups=32, eps=1e-5, residual=None):
+    """out = s * GroupNorm(y) + s (+ cat(residual.t, residual.t2)) in ONE launch (no-grad forwards); y: a plain fp32 Act or
+    a Deferred conv output, whose finishing pass (bias, activation) is folded in.  Returns a plain Act."""
+    C_ = y.c
+    dev = gamma.device
+    out = torch.empty((y.n * y.h * y.w, C_), dtype=torch.float32, device=dev)
+    mns = 0 if (mod is None or mod.shape[0] == 1) else mod.stride(0)
+    x0 = None if residual is None else residual.t
+    x1 = None if residual is None else residual.t2
+    if isinstance(y, Deferred):
+        src, ld, raw, bias, act = y.ws, C_, 1, y.bias, y.act
+    else:
+        src, ld, raw, bias, act = y.t, y.t.stride(0), 0, None, ACT_NONE
+    lib.call("sdm_gn_apply_fused", _p(src), ld, raw, 1.0, _p(bias), act, y.n, y.h * y.w, C_, groups, eps, _p(gamma), _p(beta),
+             _p(mod), mns, _p(x0), x0.stride(0) if x0 is not None else 0, _p(x1), x1.stride(0) if x1 is not None else 0,
+             residual.c1 if x1 is not None else (1 << 30), _p(out), out.stride(0), _stream())
+    return Act(out, y.n, y.h, y.w)
 
 
 def affine_residual(y, scale, shift, x):

@@ -845,3 +845,34 @@ def test_skinny_weight_streaming_kernel_opt_in():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
                         "conv_fwd_dgrad_wgrad or concat_affine"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("n,c,h,w", [(1, 128, 4, 4), (2, 128, 16, 16), (1, 256, 8, 8), (3, 128, 40, 40)])
+def test_residual_block_fused_tail_vs_oracle(dev, L, O, n, c, h, w):
+    """No-grad fp32 ResidualBlock with the fused conv-block tail (sdm_gn_apply_fused: split-K finishing pass + GroupNorm +
+    AdaGN affine + residual add in one launch), on shapes where the conv defers its epilogue (small M: split-K) and where
+    it does not (large M), batch-1 and per-image embeddings -- against the oracle's res_block and against the unfused path."""
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(n * 1000 + c + h)
+    blk = L.ResidualBlock(c, c, emb_dim=64)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.05 if p.dim() > 1 else 0.3) + (1.0 if "group_norm.weight" in "" else 0.0))
+        blk.conv_block_1.adagn.group_norm.weight.add_(1.0)
+        blk.conv_block_2.adagn.group_norm.weight.add_(1.0)
+    P = {"b." + k: v.detach().clone().contiguous() for k, v in blk.state_dict().items()}
+    x = torch.randn(n, c, h, w, generator=g)
+    for emb in (torch.randn(n, 64, generator=g), torch.randn(1, 64, generator=g)):
+        ref = O.res_block(P, "b", x, emb)
+        blk = blk.to(dev)
+        with torch.no_grad():
+            L.FUSE_GN[0] = True
+            y = blk(x.cuda(), emb.cuda())
+            L.FUSE_GN[0] = False
+            y0 = blk(x.cuda(), emb.cuda())
+            L.FUSE_GN[0] = True
+        assert rel(y, ref) < 2e-5, rel(y, ref)
+        assert rel(y0, ref) < 2e-5
+        assert rel(y, y0) < 5e-6
+    # the deferred epilogue left the shared split-K scratch zero-filled
+    assert ops.WS.buf is None or float(ops.WS.buf.abs().max()) == 0.0
