@@ -9,6 +9,7 @@
 //                            matrix-core fragments (8 consecutive k per lane) are read with ds_read_b64_tr_b16, the gfx950
 //                            transposing LDS read (two per fragment), from an XOR-swizzled image that keeps them conflict-free
 //   pointwise              : GroupNorm/AdaGN backward, column-softmax backward, SiLU backward, edge-conv gradients on bf16 rows
+#include <math.h>
 #include <stdlib.h>
 
 #include "sdm_common.h"
@@ -347,12 +348,23 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
   const int ntm = cdiv(d->M, bt);
   L.ntn = cdiv(d->N, bt);
   const long blocks = (long)ntm * L.ntn * d->ntaps * d->batch;
+  // Split over pixels by a small cost model.  The grid is tiles x 9 taps x slices, which is rarely a multiple of the
+  // chip's resident-workgroup slots (2 per CU at 128x128, 3 at 64x64): 576 workgroups of a 1024x1024 layer run as one
+  // full wave plus a 12 %-full second one and took 1.78x the time of a balanced grid (profiles/r02_c5_bf16_launches).
+  // Cost of a choice = ceil(workgroups / slots) x K-steps per slice x step time + the fp32 atomics of the extra slices
+  // (~1.3 TB/s chip-wide, MI355X_MICROARCH.md) + a per-workgroup prologue/epilogue; step times calibrated on MI355X.
   int sk = 1;
-  if (blocks < 512 && T >= 8) {
-    sk = (int)((768 + blocks - 1) / blocks);
-    if (sk > T / 4) sk = T / 4;
-    if (sk > 128) sk = 128;
-    if (sk < 1) sk = 1;
+  {
+    const double slots = big ? 512.0 : 768.0;
+    const double t_step = big ? 1.30e-6 : 0.70e-6;             // one K-step of a full wave of workgroups
+    const double out_bytes = (double)d->M * d->N * d->ntaps * d->batch * 4.0;
+    double best = 1e30;
+    for (int c = 1; c <= 128 && c <= (T >= 4 ? T / 4 : 1); ++c) {
+      const double waves = ceil((double)blocks * c / slots);
+      const double steps = ceil((double)T / c);
+      const double t = waves * (steps * t_step + 2.0e-6) + (c > 1 || d->accumulate == 1 ? out_bytes * c / 1.3e12 : out_bytes / 5e12);
+      if (t < best * 0.97) { best = t; sk = c; }               // prefer fewer slices unless it pays >= 3 %
+    }
   }
   static const char* force = getenv("SDM_WGRAD_BF16_FORCE");   // "bt,splitk" tuning override
   int fbt = 0, fsk = 0;
