@@ -9,6 +9,7 @@
 // GroupNorm/AdaGN affine applied in registers) -> LDS, double-buffered; fragments are read
 // with ds_read_b128 from rows padded to 36 floats (conflict-free) or, for operands whose
 // reduction index is the row index, with ds_read_b32 down the columns (also conflict-free).
+#include <math.h>
 #include <stdlib.h>
 
 #include "sdm_common.h"
@@ -1547,12 +1548,31 @@ extern "C" int sdm_wgrad(const sdm_wgrad_desc* d, sdm_stream_t stream) {
   const int ntm = cdiv(d->M, bt);
   L.ntn = cdiv(d->N, bt);
   const long blocks = (long)ntm * L.ntn * d->ntaps * d->batch;
+  // Split over pixels by a small cost model (same reasoning as wgrad_bf16 in sdm_bf16_train.hip): tiles x taps x slices
+  // is rarely a multiple of the resident-workgroup slots, and a 12 %-full trailing wave costs a whole wave.  Cost =
+  // ceil(workgroups / slots) x (K-steps per slice x step time + fixed) + fp32 atomics of the extra slices at ~1.3 TB/s.
   int sk = 1;
-  if (blocks < 512 && T >= 16) {
-    sk = (int)((768 + blocks - 1) / blocks);
-    if (sk > T / 8) sk = T / 8;
-    if (sk > 128) sk = 128;
-    if (sk < 1) sk = 1;
+  {
+    static const char* legacy = getenv("SDM_WGRAD_PLAN");     // "0": the round-1 rule (A/B)
+    if (legacy && legacy[0] == '0') {
+      if (blocks < 512 && T >= 16) {
+        sk = (int)((768 + blocks - 1) / blocks);
+        if (sk > T / 8) sk = T / 8;
+        if (sk > 128) sk = 128;
+        if (sk < 1) sk = 1;
+      }
+    } else {
+      const double slots = big ? 512.0 : 768.0;
+      const double t_step = big ? 3.7e-6 : 1.3e-6;            // one 32-pixel K-step of a full wave of workgroups
+      const double out_bytes = (double)d->M * d->N * d->ntaps * d->batch * 4.0;
+      double best = 1e30;
+      for (int c = 1; c <= 128 && c <= (T >= 8 ? T / 8 : 1); ++c) {
+        const double waves = ceil((double)blocks * c / slots);
+        const double steps = ceil((double)T / c);
+        const double t = waves * (steps * t_step + 3.0e-6) + (c > 1 || d->accumulate == 1 ? out_bytes * c / 1.3e12 : out_bytes / 5e12);
+        if (t < best * 0.97) { best = t; sk = c; }
+      }
+    }
   }
   L.splitk = sk;
   L.atomic_out = (sk > 1 || d->accumulate == 1) ? 1 : 0;
