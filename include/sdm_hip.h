@@ -359,6 +359,9 @@ int sdm_stem_conv_bf16(const float* x_nchw, const float* w_tap, const float* bia
                        int images, int Cin, int H, int W, int Cout, int act, sdm_stream_t s);
 int sdm_head_conv_bf16(const uint16_t* x_nhwc, const float* w_tap, const float* bias, float* out_nchw,
                        int images, int Cin, int H, int W, int Cout, int act, sdm_stream_t s);
+/* fp32 rows [images*H*W][ld] (first C columns) -> NCHW fp32: lays out the head conv's result as the reference returns it
+ * when out_layers.1 runs on the matrix cores (sdm_igemm_bf16 with fp32 output). */
+int sdm_rows_to_nchw(const float* rows, int64_t ld, float* out_nchw, int images, int C, int H, int W, sdm_stream_t s);
 /* sdm_gn_affine on bf16 rows (fp32 tables out); mean / rstd [images][groups] are optional (both or neither): the training
  * path's backward needs them, sampling passes NULL. */
 int sdm_gn_affine_bf16(const uint16_t* y, int64_t ldy, int images, int HW, int C, int groups, float eps,

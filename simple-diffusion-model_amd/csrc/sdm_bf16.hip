@@ -428,6 +428,7 @@ static void bf_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* ws_n
   const long t128 = (long)cdiv(d->M, 128) * cdiv(d->N, 128) * ph;
   const long t64 = (long)cdiv(d->M, 64) * cdiv(d->N, 64) * ph;
   int c = t128 >= 320 ? 0 : 1, sk = 1;
+  if (d->N <= 64) c = 1;     // the 3-channel head conv: a 128-wide tile would be 98 % padding, a 64-wide one 95 %
   if (c == 1 && t64 < 512) {
     sk = (int)((512 + t64 - 1) / t64);
     if (sk > T / 4) sk = T / 4;
@@ -893,5 +894,27 @@ extern "C" int sdm_transpose_bf16(const uint16_t* src, int64_t ld_src, int64_t s
                      (long long)ld_src, (long long)src_bs0, (long long)src_bs1, bdiv, dst, (long long)ld_dst,
                      (long long)dst_bs, R, Cc);
   SDM_CHECK_LAUNCH("transpose_bf16");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// fp32 rows [images*HW][ld] (first C columns) -> NCHW fp32 [images][C][HW]: the edge of the matrix-core head conv
+// (out_layers.1 evaluated by sdm_igemm_bf16 with fp32 output, then laid out as the reference returns it).
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_to_nchw_kernel(const float* __restrict__ rows, long long ld, float* __restrict__ out,
+                                                           int C, long long HW, long long P) {
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long long)gridDim.x * 256) {
+    const long long n = p / HW, rem = p - n * HW;
+    for (int c = 0; c < C; ++c) out[(n * C + c) * HW + rem] = rows[p * ld + c];
+  }
+}
+
+extern "C" int sdm_rows_to_nchw(const float* rows, int64_t ld, float* out_nchw, int images, int C, int H, int W, sdm_stream_t s) {
+  SDM_CHECK_ARG(rows && out_nchw && images > 0 && C > 0 && H > 0 && W > 0 && ld >= C, "rows_to_nchw: bad args");
+  const long long HW = (long long)H * W, P = HW * images;
+  int grid = (int)((P + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(rows_to_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, rows, (long long)ld, out_nchw, C, HW, P);
+  SDM_CHECK_LAUNCH("rows_to_nchw");
   return SDM_OK;
 }

@@ -174,7 +174,8 @@ class U_Net(nn.Module):
         head = self.out_layers[1].conv_layer.conv
         if ctx.train:
             ctx.rec["head_in"] = a
-        return ops.head_conv(a, head.taps(), head.bias, ACT_TANH if self.image_recon else ACT_NONE)
+        return ops.head_conv(a, head.taps(), head.bias, ACT_TANH if self.image_recon else ACT_NONE,
+                             wt16=head.taps_for(ctx) if ctx.bf16 else None)
 
     def forward(self, x, t=None, cond=None):
         self._check_input(x)

@@ -721,9 +721,28 @@ def stem_conv(x_nchw, wt, bias, act=ACT_SILU, save_z=False, out_dtype=torch.floa
     return Act(out, n, h, w, z=z)
 
 
-def head_conv(x, wt, bias, act=ACT_NONE):
+HEAD_MFMA = [True]      # bf16 rows: head conv on the matrix cores (False: the one-wave-per-pixel kernel)
+
+
+def head_conv(x, wt, bias, act=ACT_NONE, wt16=None):
+    """out_layers.1: rows [n*h*w, c] -> NCHW fp32 [n, c_out, h, w] (+Tanh).  bf16 rows with ``wt16`` (bf16 taps
+    [9, c_out, c]): the contraction runs on sdm_igemm_bf16 with an fp32 result (c_out = 3 of a 64-wide tile: wasteful per
+    FLOP, 3x faster than one wave per pixel at 128x128 / 256x256), then one pass lays the rows out as NCHW."""
     cout = wt.shape[1]
     out = torch.empty((x.n, cout, x.h, x.w), dtype=torch.float32, device=wt.device)
+    if x.t.dtype == BF16 and wt16 is not None and HEAD_MFMA[0] and x.c % 8 == 0:
+        rows = torch.empty((x.rows, 4 * ((cout + 3) // 4)), dtype=torch.float32, device=wt.device)
+        d = _base_desc(x.rows, cout, x.c)
+        d.Ht, d.Wt = x.h, x.w
+        _set_taps(d, 0, _C3_COLS)
+        fill_rows(d.a, x)
+        d.b, d.ldb, d.b_tap_stride, d.b_kmajor = _p(wt16), x.c, cout * x.c, 0
+        d.Ho, d.Wo = x.h, x.w
+        d.out, d.ldo = _p(rows), rows.stride(0)
+        d.bias, d.act = _p(bias), act
+        _launch_igemm(d, wt.device, bf16=True, out_f32=True)
+        lib.call("sdm_rows_to_nchw", _p(rows), rows.stride(0), _p(out), x.n, cout, x.h, x.w, _stream())
+        return out
     if x.t.dtype == BF16:
         lib.call("sdm_head_conv_bf16", _p(x.t), _p(wt), _p(bias), _p(out), x.n, x.c, x.h, x.w, cout, act, _stream())
         return out
