@@ -359,6 +359,13 @@ int sdm_stem_conv_bf16(const float* x_nchw, const float* w_tap, const float* bia
                        int images, int Cin, int H, int W, int Cout, int act, sdm_stream_t s);
 int sdm_head_conv_bf16(const uint16_t* x_nhwc, const float* w_tap, const float* bias, float* out_nchw,
                        int images, int Cin, int H, int W, int Cout, int act, sdm_stream_t s);
+/* sdm_gn_apply_fused on bf16 rows: src = the conv's finished bf16 rows (src_raw 0, pitch ld_src in elements) or the fp32
+ * raw split-K sums left by sdm_igemm_bf16(defer_epilogue = 1) (src_raw 1; rounded to bf16 after bias / activation, as the
+ * unfused path does, and cleared); x0 / x1 / out bf16. */
+int sdm_gn_apply_fused_bf16(const void* src, int64_t ld_src, int src_raw, float alpha, const float* bias, int act,
+                            int images, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
+                            const float* mod, int mod_nstride, const uint16_t* x0, int64_t ldx0, const uint16_t* x1,
+                            int64_t ldx1, int csplit, uint16_t* out, int64_t ldo, sdm_stream_t s);
 /* fp32 rows [images*H*W][ld] (first C columns) -> NCHW fp32: lays out the head conv's result as the reference returns it
  * when out_layers.1 runs on the matrix cores (sdm_igemm_bf16 with fp32 output). */
 int sdm_rows_to_nchw(const float* rows, int64_t ld, float* out_nchw, int images, int C, int H, int W, sdm_stream_t s);

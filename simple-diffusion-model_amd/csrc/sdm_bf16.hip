@@ -406,6 +406,8 @@ static int bf_validate(const sdm_igemm_desc* d, int out_f32) {
   SDM_CHECK_ARG(!(out_f32 && (d->res || d->res2 || d->out_preact)), "igemm_bf16: fp32 output takes no residual / pre-activation copy");
   SDM_CHECK_ARG(d->ostride >= 1 && d->sstride >= 1 && d->Ho > 0 && d->Wo > 0, "igemm_bf16: bad strides/output dims");
   SDM_CHECK_ARG(d->act >= 0 && d->act <= 2, "igemm_bf16: bad act");
+  SDM_CHECK_ARG(!d->defer_epilogue || (d->batch == 1 && !d->res && !d->res2 && !d->out_preact && !d->dact_z && !out_f32),
+                "igemm_bf16: a deferred epilogue carries only alpha / bias / activation (batch 1, bf16 output)");
   return SDM_OK;
 }
 
@@ -523,6 +525,7 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
   if (cfg == 0) rc = fast ? launch_bf<128, 128, 2, 2, 2, true>(L, ntm, st) : launch_bf<128, 128, 2, 2, 2, false>(L, ntm, st);
   else rc = fast ? launch_bf<64, 64, 2, 2, 3, true>(L, ntm, st) : launch_bf<64, 64, 2, 2, 3, false>(L, ntm, st);
   if (rc != SDM_OK) return rc;
+  if (L.splitk > 1 && d->defer_epilogue) return SDM_DEFERRED;   // raw fp32 sums stay in ws for sdm_gn_apply_fused_bf16
   if (L.splitk > 1) {
     const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
     const long long total = (long long)out_rows * d->batch * d->N;
@@ -916,5 +919,129 @@ extern "C" int sdm_rows_to_nchw(const float* rows, int64_t ld, float* out_nchw, 
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(rows_to_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, rows, (long long)ld, out_nchw, C, HW, P);
   SDM_CHECK_LAUNCH("rows_to_nchw");
+  return SDM_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// Fused conv-block tail on bf16 rows (no-grad forwards; see gn_apply_fused_kernel in sdm_pointwise.hip): src is either
+// the conv's finished bf16 rows or the fp32 raw split-K sums left by sdm_igemm_bf16(defer_epilogue); out and the
+// residual are bf16; statistics of the VALUES THE NEXT LAYER SEES (i.e. after rounding y to bf16, like the unfused path).
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 gnf16_value(const void* __restrict__ src, long long idx, int raw, float alpha, const f32x4 b,
+                                             int act) {
+  f32x4 v;
+  if (raw) {
+    v = *(const f32x4*)((const float*)src + idx);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = bf2f(f2bf(sdm_act(v[i] * alpha + b[i], act)));
+  } else {
+    const u16x4 u = *(const u16x4*)((const bf16_t*)src + idx);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = bf2f(u[i]);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(1024) void gn_apply_fused_bf16_kernel(void* __restrict__ src, long long lds_, int raw, float alpha,
+                                                                   const float* __restrict__ bias, int act, int HW, int C,
+                                                                   int groups, float eps, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta,
+                                                                   const float* __restrict__ mod, int mod_ns,
+                                                                   const bf16_t* __restrict__ x0, long long ldx0,
+                                                                   const bf16_t* __restrict__ x1, long long ldx1, int csplit,
+                                                                   bf16_t* __restrict__ out, long long ldo) {
+  __shared__ double red[2][16];
+  __shared__ float s_stat[2];
+  const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cpg = C / groups, q4 = cpg >> 2;
+  const long long base = (long long)n * HW * lds_ + g * cpg;
+  const long long tot4 = (long long)HW * q4;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  double s1 = 0.0, s2 = 0.0;
+  for (long long e0 = threadIdx.x; e0 < tot4; e0 += 1024 * 8) {
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long e = e0 + (long long)u * 1024;
+      if (e < tot4) {
+        const long long pix = e / q4;
+        const int c = (int)(e - pix * q4) * 4;
+        const f32x4 b = (raw && bias) ? *(const f32x4*)(bias + g * cpg + c) : zero4;
+        const f32x4 v = gnf16_value(src, base + pix * lds_ + c, raw, alpha, b, act);
+        p1 += (v.x + v.y) + (v.z + v.w);
+        p2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    }
+    s1 += p1;
+    s2 += p2;
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { a += red[0][w]; b += red[1][w]; }
+    const double total = (double)HW * cpg;
+    const double mean = a / total;
+    double var = b / total - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_stat[0] = (float)mean;
+    s_stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const float mu = s_stat[0], rstd = s_stat[1];
+  for (long long e = threadIdx.x; e < tot4; e += 1024) {
+    const long long pix = e / q4;
+    const int c = (int)(e - pix * q4) * 4;
+    const int ch = g * cpg + c;
+    const long long si = base + pix * lds_ + c;
+    const f32x4 b = (raw && bias) ? *(const f32x4*)(bias + ch) : zero4;
+    const f32x4 v = gnf16_value(src, si, raw, alpha, b, act);
+    if (raw) *(f32x4*)((float*)src + si) = zero4;        // the split-K scratch goes back zero-filled
+    const f32x4 ga = *(const f32x4*)(gamma + ch), be = *(const f32x4*)(beta + ch);
+    f32x4 o;
+    if (mod) {
+      const f32x4 sm = *(const f32x4*)(mod + (long long)n * mod_ns + ch);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = v[i] * (rstd * ga[i] * sm[i]) + ((be[i] - mu * rstd * ga[i]) * sm[i] + sm[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = v[i] * (rstd * ga[i]) + (be[i] - mu * rstd * ga[i]);
+    }
+    const long long row = (long long)n * HW + pix;
+    if (x0) {
+      const u16x4 xv = (ch < csplit) ? *(const u16x4*)(x0 + row * ldx0 + ch) : *(const u16x4*)(x1 + row * ldx1 + (ch - csplit));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] += bf2f(xv[i]);
+    }
+    u16x4 ov;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ov[i] = f2bf(o[i]);
+    *(u16x4*)(out + row * ldo + ch) = ov;
+  }
+}
+
+extern "C" int sdm_gn_apply_fused_bf16(const void* src, int64_t ld_src, int src_raw, float alpha, const float* bias, int act,
+                                       int images, int HW, int C, int groups, float eps, const float* gamma,
+                                       const float* beta, const float* mod, int mod_nstride, const uint16_t* x0,
+                                       int64_t ldx0, const uint16_t* x1, int64_t ldx1, int csplit, uint16_t* out, int64_t ldo,
+                                       sdm_stream_t s) {
+  SDM_CHECK_ARG(src && gamma && beta && out && images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_apply_fused_bf16: bad args");
+  SDM_CHECK_ARG(x0 == nullptr || x1 != nullptr || csplit >= C, "gn_apply_fused_bf16: csplit < C without second source");
+  const int cpg = C / groups;
+  auto al = [](const void* q, size_t a) { return (((uintptr_t)q) & (a - 1)) == 0; };
+  SDM_CHECK_ARG(cpg % 4 == 0 && ld_src % 4 == 0 && ldo % 4 == 0 && al(src, src_raw ? 16 : 8) && al(out, 8) && aligned16(gamma) &&
+                    aligned16(beta) && (mod == nullptr || (aligned16(mod) && mod_nstride % 4 == 0)) &&
+                    (bias == nullptr || aligned16(bias)) && (x0 == nullptr || (al(x0, 8) && ldx0 % 4 == 0 && csplit % 4 == 0)) &&
+                    (x1 == nullptr || (al(x1, 8) && ldx1 % 4 == 0)),
+                "gn_apply_fused_bf16: needs channels-per-group %% 4 == 0 and aligned rows / tables");
+  SDM_CHECK_ARG(act >= 0 && act <= 2, "gn_apply_fused_bf16: bad act");
+  hipLaunchKernelGGL(gn_apply_fused_bf16_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, (void*)src,
+                     (long long)ld_src, src_raw, alpha, bias, act, HW, C, groups, eps, gamma, beta, mod, mod_nstride,
+                     (const bf16_t*)x0, (long long)ldx0, (const bf16_t*)x1, (long long)ldx1, csplit, (bf16_t*)out, (long long)ldo);
+  SDM_CHECK_LAUNCH("gn_apply_fused_bf16");
   return SDM_OK;
 }

@@ -53,7 +53,9 @@ class RunCtx:
 
 
 MATERIALIZE_TRAIN = [os.environ.get("SDM_TRAIN_MATERIALIZE", "1") != "0"]
-FUSE_GN = [os.environ.get("SDM_FUSE_GN", "1") != "0"]       # fused conv-block tail in no-grad fp32 forwards
+FUSE_GN = [os.environ.get("SDM_FUSE_GN", "1") != "0"]       # fused conv-block tail in no-grad forwards
+FUSE_GN_BF16 = [os.environ.get("SDM_FUSE_GN_BF16", "0") == "1"]   # bf16 rows: measured neutral (N=1 0.97 -> 0.99 ms): opt-in
+FUSE_GN_MAX_BYTES = 8 << 20                                   # ... for conv outputs up to 8 MB (see ResidualBlock._fuse_this)
 
 
 def bf16_weight(mod, key, src_fn, transposed=False, pad_to=1):
@@ -438,7 +440,7 @@ class UNet_ConvBlock(nn.Module):
         c = self.conv_layer.conv
         act = ACT_SILU if self.use_activation else ACT_NONE
         mod = ctx.mods[self.adagn] if ctx.mods is not None else self.adagn.modulation(emb)
-        y = ops.conv_fwd(x, c.taps(), c.bias, "c3s1", act, defer=True)     # nothing may touch the scratch until it is consumed
+        y = ops.conv_fwd(x, c.taps_for(ctx), c.bias, "c3s1", act, defer=True)   # nothing may touch the scratch until consumed
         gn = self.adagn.group_norm
         return ops.gn_apply_fused(y, gn.weight, gn.bias, mod, gn.groups, residual=residual)
 
@@ -467,18 +469,29 @@ class ResidualBlock(nn.Module):
         self.shortcut = nn.Identity()
 
     def _fusable(self, ctx, emb):
-        """No-grad fp32 forward with AdaGN on both conv blocks and GroupNorm groups of a multiple of 4 channels: the tail
-        of each conv block (split-K finishing pass, GroupNorm fold, affine, residual add) runs as ONE launch."""
-        if ctx.train or ctx.bf16 or emb is None or not FUSE_GN[0]:
+        """No-grad forward (fp32 or bf16 rows) with AdaGN on both conv blocks and GroupNorm groups of a multiple of 4
+        channels: the tail of each conv block (split-K finishing pass, GroupNorm fold, affine, residual add) runs as ONE
+        launch."""
+        if ctx.train or emb is None or not FUSE_GN[0] or (ctx.bf16 and not FUSE_GN_BF16[0]):
+            return False
+        return True
+
+    def _fuse_this(self, ctx, x, emb):
+        """The fused tail runs ONE workgroup per (image, group) over that slice twice: it wins where the step is a chain of
+        small dependent launches (N=1..4 sampling: -24 launches per step), and loses to the separate, wider kernels once
+        a conv output no longer sits in L2 (measured: 128x128 batch-128 bf16 forward 35.4 -> 40.3 ms) -> small outputs only."""
+        if not self._fusable(ctx, emb):
             return False
         a1, a2 = getattr(self.conv_block_1, "adagn", None), getattr(self.conv_block_2, "adagn", None)
         if a1 is None or a2 is None:
             return False
         c = self.conv_block_1.conv_layer.conv.cout
+        if x.rows * c * (2 if ctx.bf16 else 4) > FUSE_GN_MAX_BYTES:
+            return False
         return c % (4 * a1.group_norm.groups) == 0 and c % (4 * a2.group_norm.groups) == 0
 
     def run(self, ctx, x, emb=None):
-        if self._fusable(ctx, emb):
+        if self._fuse_this(ctx, x, emb):
             x2 = self.conv_block_1.run_fused(ctx, x, emb)
             return self.conv_block_2.run_fused(ctx, x2, emb, residual=x)
         y1, aff1 = self.conv_block_1.run(ctx, x, emb)

@@ -131,6 +131,7 @@ _PROTOS = {
     "sdm_gn_affine_bf16": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, fp, fp, fp, fp]),
     "sdm_affine_residual_bf16": (_i, [fp, _i64, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, _i, _i, _i, fp]),
     "sdm_col_softmax_bf16": (_i, [fp, fp, _i, _i, _i64, _i64, fp]),
+    "sdm_gn_apply_fused_bf16": (_i, [fp, _i64, _i, _f, fp, _i, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, fp]),
     "sdm_rows_to_nchw": (_i, [fp, _i64, fp, _i, _i, _i, _i, fp]),
     "sdm_transpose_bf16": (_i, [fp, _i64, _i64, _i64, _i, fp, _i64, _i64, _i, _i, _i, fp]),
     # bf16 training path

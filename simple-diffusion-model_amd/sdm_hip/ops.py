@@ -243,10 +243,10 @@ class Deferred:
     """A conv output whose split-K finishing pass has NOT run: raw sums [rows, c] in the shared zero-filled scratch
     (WS.buf), plus what the finishing pass would have applied.  Consumed -- and the scratch cleared -- by the very next
     launch (gn_apply_fused); nothing else may touch WS in between."""
-    __slots__ = ("ws", "n", "h", "w", "c", "bias", "act")
+    __slots__ = ("ws", "n", "h", "w", "c", "bias", "act", "dtype")
 
-    def __init__(self, ws, n, h, w, c, bias, act):
-        self.ws, self.n, self.h, self.w, self.c, self.bias, self.act = ws, n, h, w, c, bias, act
+    def __init__(self, ws, n, h, w, c, bias, act, dtype=torch.float32):
+        self.ws, self.n, self.h, self.w, self.c, self.bias, self.act, self.dtype = ws, n, h, w, c, bias, act, dtype
 
 
 def to_bf16(t, out=None):
@@ -331,9 +331,9 @@ def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False, defer=False):
     d.Ho, d.Wo = ho, wo
     d.out, d.ldo = _p(out), out.stride(0)
     d.bias, d.act, d.out_preact = _p(bias), act, _p(z)
-    d.defer_epilogue = int(bool(defer) and not bf and not save_z)
+    d.defer_epilogue = int(bool(defer) and not save_z)
     if _launch_igemm(d, wt.device, bf16=bf) == lib.DEFERRED:
-        return Deferred(WS.buf, x.n, ho, wo, cout, bias, act)
+        return Deferred(WS.buf, x.n, ho, wo, cout, bias, act, BF16 if bf else torch.float32)
     return Act(out, x.n, ho, wo, z=z)
 
 
@@ -777,7 +777,8 @@ def gn_apply_fused(y, gamma, beta, mod, groups=32, eps=1e-5, residual=None):
     a Deferred conv output, whose finishing pass (bias, activation) is folded in.  Returns a plain Act."""
     C_ = y.c
     dev = gamma.device
-    out = torch.empty((y.n * y.h * y.w, C_), dtype=torch.float32, device=dev)
+    dt = y.dtype if isinstance(y, Deferred) else y.t.dtype
+    out = torch.empty((y.n * y.h * y.w, C_), dtype=dt, device=dev)
     mns = 0 if (mod is None or mod.shape[0] == 1) else mod.stride(0)
     x0 = None if residual is None else residual.t
     x1 = None if residual is None else residual.t2
@@ -785,7 +786,7 @@ def gn_apply_fused(y, gamma, beta, mod, groups=32, eps=1e-5, residual=None):
         src, ld, raw, bias, act = y.ws, C_, 1, y.bias, y.act
     else:
         src, ld, raw, bias, act = y.t, y.t.stride(0), 0, None, ACT_NONE
-    lib.call("sdm_gn_apply_fused", _p(src), ld, raw, 1.0, _p(bias), act, y.n, y.h * y.w, C_, groups, eps, _p(gamma), _p(beta),
+    lib.call("sdm_gn_apply_fused_bf16" if dt == BF16 else "sdm_gn_apply_fused", _p(src), ld, raw, 1.0, _p(bias), act, y.n, y.h * y.w, C_, groups, eps, _p(gamma), _p(beta),
              _p(mod), mns, _p(x0), x0.stride(0) if x0 is not None else 0, _p(x1), x1.stride(0) if x1 is not None else 0,
              residual.c1 if x1 is not None else (1 << 30), _p(out), out.stride(0), _stream())
     return Act(out, y.n, y.h, y.w)

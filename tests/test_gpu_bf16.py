@@ -247,3 +247,32 @@ def test_bf16_weights_follow_the_optimizer(dev, O):
         y1_32 = net(x, t)
     assert rel(y1, y0) > 2e-3                # the step moved the weights and the bf16 forward saw it
     assert rel(y1, y1_32) < 1e-2
+
+
+@pytest.mark.parametrize("n,c,h,w", [(1, 128, 4, 4), (2, 128, 16, 16), (2, 256, 24, 24)])
+def test_residual_block_fused_tail_bf16(dev, n, c, h, w):
+    """bf16 rows: the fused conv-block tail (sdm_gn_apply_fused_bf16, with and without a deferred split-K epilogue) against
+    the unfused bf16 path (same roundings: equal up to summation order) and the fp32 path (bf16 storage noise)."""
+    from models import custom_layers as L
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(n * 100 + c + h)
+    blk = L.ResidualBlock(c, c, emb_dim=64)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.05 if p.dim() > 1 else 0.3))
+        blk.conv_block_1.adagn.group_norm.weight.add_(1.0)
+        blk.conv_block_2.adagn.group_norm.weight.add_(1.0)
+    blk = blk.to(dev)
+    x = torch.randn(n * h * w, c, generator=g).cuda()
+    emb = torch.randn(n, 64, generator=g).cuda()
+    with torch.no_grad():
+        ref32 = blk.run(L.RunCtx(False), ops.Act(x, n, h, w), emb).t
+        L.FUSE_GN_BF16[0] = True                  # opt-in on bf16 rows (measured neutral for the sampling step)
+        fused = blk.run(L.RunCtx(False, bf16=True), ops.Act(x.to(torch.bfloat16), n, h, w), emb).t
+        L.FUSE_GN_BF16[0] = False
+        plain = blk.run(L.RunCtx(False, bf16=True), ops.Act(x.to(torch.bfloat16), n, h, w), emb).t
+    torch.cuda.synchronize()
+    assert fused.dtype == torch.bfloat16
+    assert rel(fused, plain) < 4e-3, rel(fused, plain)
+    assert rel(fused, ref32) < 1e-2, rel(fused, ref32)
+    assert ops.WS.buf is None or float(ops.WS.buf.abs().max()) == 0.0
