@@ -142,6 +142,12 @@ typedef struct sdm_igemm_desc {
                              CONTRACT: the caller hands it over zero-filled once; every call leaves the part it
                              touched zero-filled again (the finishing pass clears what it reads) */
   size_t ws_bytes;
+  float* gn_sums;         /* sdm_igemm_bf16 only; NULL or ZERO-FILLED fp32 [images][N][2]: the epilogue adds, per (image, output
+                             channel), the sum and the sum of squares of the values it stores (after activation and bf16
+                             rounding) -- the GroupNorm statistics of the conv's output without another pass over it
+                             (SURVEY §7 step 5).  Done only for an unsplit plain 3x3 stride-1 conv whose tiles lie inside
+                             one image; the call then returns SDM_STATS_DONE and sdm_gn_finalize turns the sums into the
+                             affine tables; otherwise the sums stay untouched (zero) and the caller runs sdm_gn_affine_bf16. */
   int defer_epilogue;     /* 1: if the library splits K, it leaves the RAW sums in ws ([out row][N], alpha / bias / act not yet
                              applied) and returns SDM_DEFERRED instead of running its finishing pass: the caller's next
                              kernel finishes them (sdm_gn_apply_fused folds the finishing pass into the GroupNorm that
@@ -150,6 +156,7 @@ typedef struct sdm_igemm_desc {
 } sdm_igemm_desc;
 
 #define SDM_DEFERRED 1
+#define SDM_STATS_DONE 2
 int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream);
 /* scratch the library may want for this problem (0 if it will not split K) */
 size_t sdm_igemm_workspace_bytes(const sdm_igemm_desc* d);
@@ -366,6 +373,11 @@ int sdm_gn_apply_fused_bf16(const void* src, int64_t ld_src, int src_raw, float 
                             int images, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
                             const float* mod, int mod_nstride, const uint16_t* x0, int64_t ldx0, const uint16_t* x1,
                             int64_t ldx1, int csplit, uint16_t* out, int64_t ldo, sdm_stream_t s);
+/* GroupNorm + AdaGN fold (the tables of sdm_gn_affine) from the per-(image, channel) {sum, sum of squares} a conv epilogue
+ * emitted (sdm_igemm_desc.gn_sums): no pass over the activation.  The sums are cleared again (zero-filled contract).  mean /
+ * rstd optional (training). */
+int sdm_gn_finalize(float* sums, int images, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
+                    const float* mod, int mod_nstride, float* scale, float* shift, float* mean, float* rstd, sdm_stream_t s);
 /* fp32 rows [images*H*W][ld] (first C columns) -> NCHW fp32: lays out the head conv's result as the reference returns it
  * when out_layers.1 runs on the matrix cores (sdm_igemm_bf16 with fp32 output). */
 int sdm_rows_to_nchw(const float* rows, int64_t ld, float* out_nchw, int images, int C, int H, int W, sdm_stream_t s);

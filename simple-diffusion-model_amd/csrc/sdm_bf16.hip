@@ -20,6 +20,7 @@ struct BfLaunch {
   sdm_igemm_desc d;
   int splitk, ntn, kchunks, mfast, out_f32;
   int vec_epi;   // 4-column vector epilogue allowed (N % 4 == 0, 8-byte aligned output / residual rows, 16-byte bias)
+  int gn_stats;  // accumulate per-(image, channel) sum / sum of squares of the stored outputs into d.gn_sums
   long long out_rows;   // output rows of ONE batch entry (split-K scratch is [batch][out_rows][N])
 };
 
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
         }
     __syncthreads();
     constexpr int C4 = BN / 4;
+    f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};     // GroupNorm statistics of this thread's 4 columns
 #pragma unroll 2
     for (int e = tid; e < BM * C4; e += NT) {
       const int row = e / C4, c4 = (e - row * C4) * 4;
@@ -328,6 +330,38 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = f2bf(v[q]);
         *(u16x4*)(out16 + obo + orow * d.ldo + col) = o;
+        if (L.gn_stats) {       // statistics of the values the next layer will read (after rounding to bf16)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float r = bf2f(o[q]);
+            gs[q] += r;
+            gq[q] = fmaf(r, r, gq[q]);
+          }
+        }
+      }
+    }
+    if (L.gn_stats) {
+      // NT / C4 threads share a column quad (rows e / C4 differ by NT / C4): fold them through LDS (the staged tile is
+      // dead now), then one fp32 atomic pair per column and workgroup into [image][channel][2].  The host guarantees that
+      // a tile's rows lie in ONE image (Ho*Wo % BM == 0) and that output rows are tile rows (plain 3x3 stride-1 conv).
+      constexpr int GT = NT / C4;
+      __syncthreads();
+      float* red = smem;
+      *(f32x4*)(red + (tid * 2) * 4) = gs;
+      *(f32x4*)(red + (tid * 2 + 1) * 4) = gq;
+      __syncthreads();
+      if (tid < BN && n0 + tid < N && s_orow[0] >= 0) {
+        const int cg = tid >> 2, q = tid & 3;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+          a += red[((g * C4 + cg) * 2) * 4 + q];
+          b += red[((g * C4 + cg) * 2 + 1) * 4 + q];
+        }
+        const long long img = s_orow[0] / ((long long)d.Ho * d.Wo);
+        float* dst = d.gn_sums + (img * N + n0 + tid) * 2;
+        atomicAdd(dst, a);
+        atomicAdd(dst + 1, b);
       }
     }
     return;
@@ -520,12 +554,17 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
     const double mfast = (double)(c < ntm ? c : ntm) * a_tile + (double)cdiv(c, ntm) * b_tile;
     L.mfast = mfast < nfast ? 1 : 0;
   }
+  // GroupNorm statistics in the epilogue: vector epilogue, no split, plain row order, tiles inside one image
+  L.gn_stats = d->gn_sums != nullptr && !out_f32 && L.vec_epi && L.splitk == 1 && d->batch == 1 && d->nphase == 1 &&
+               d->ostride == 1 && d->sstride == 1 && d->Ht == d->Ho && d->Wt == d->Wo && d->N % 4 == 0 &&
+               ((long)d->Ho * d->Wo) % kBfCfgs[cfg].bm == 0;
   static const char* nofast = getenv("SDM_BF16_FAST");
   const bool fast = d->K % BKE == 0 && (d->a.p1 == nullptr || d->a.csplit % BKE == 0) && !(nofast && nofast[0] == '0');
   if (cfg == 0) rc = fast ? launch_bf<128, 128, 2, 2, 2, true>(L, ntm, st) : launch_bf<128, 128, 2, 2, 2, false>(L, ntm, st);
   else rc = fast ? launch_bf<64, 64, 2, 2, 3, true>(L, ntm, st) : launch_bf<64, 64, 2, 2, 3, false>(L, ntm, st);
   if (rc != SDM_OK) return rc;
   if (L.splitk > 1 && d->defer_epilogue) return SDM_DEFERRED;   // raw fp32 sums stay in ws for sdm_gn_apply_fused_bf16
+  if (L.gn_stats) return SDM_STATS_DONE;
   if (L.splitk > 1) {
     const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
     const long long total = (long long)out_rows * d->batch * d->N;
@@ -822,16 +861,31 @@ extern "C" int sdm_affine_residual_bf16(const uint16_t* y, int64_t ldy, const fl
 // column softmax of fp32 scores [batch][S][lds] -> bf16 probabilities [batch][S][ldp] (softmax over rows i for every
 // column j, custom_layers.py:147).  Columns j in [S, ldp) are written as zero (they are reduction padding for P.V).
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void col_softmax_bf16_kernel(const float* __restrict__ sc, bf16_t* __restrict__ P, int S,
-                                                               long long lds, long long ldp) {
-  __shared__ float sm[4][64], ss[4][64];
+// CSM_W row phases (waves) per workgroup, lane = column: S = 4096 x 8 images is 1.3 GB of traffic per call, and with 4
+// phases of one outstanding load each it streamed at 1.3 TB/s; 16 phases x 4 independent rows per lane keep 64 loads per
+// column block in flight.
+#define CSM_W 16
+__global__ __launch_bounds__(64 * CSM_W) void col_softmax_bf16_kernel(const float* __restrict__ sc, bf16_t* __restrict__ P, int S,
+                                                                      long long lds, long long ldp) {
+  __shared__ float sm[CSM_W][64], ss[CSM_W][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + lane;
   const float* base = sc + (long long)blockIdx.y * S * lds;
   bf16_t* pb = P + (long long)blockIdx.y * S * ldp;
   float m = -INFINITY, l = 0.f;
   if (j < S) {
-    for (int i = wave; i < S; i += 4) {
+    int i = wave;
+    for (; i + 3 * CSM_W < S; i += 4 * CSM_W) {       // four independent rows per trip: their loads overlap
+      const float v0 = base[(long long)i * lds + j], v1 = base[(long long)(i + CSM_W) * lds + j];
+      const float v2 = base[(long long)(i + 2 * CSM_W) * lds + j], v3 = base[(long long)(i + 3 * CSM_W) * lds + j];
+      const float vm = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+      if (vm > m) {
+        l *= __expf(m - vm);
+        m = vm;
+      }
+      l += (__expf(v0 - m) + __expf(v1 - m)) + (__expf(v2 - m) + __expf(v3 - m));
+    }
+    for (; i < S; i += CSM_W) {
       const float v = base[(long long)i * lds + j];
       if (v > m) {
         l = l * __expf(m - v) + 1.f;
@@ -844,23 +898,34 @@ __global__ __launch_bounds__(256) void col_softmax_bf16_kernel(const float* __re
   sm[wave][lane] = m;
   ss[wave][lane] = l;
   __syncthreads();
-  const float M = fmaxf(fmaxf(sm[0][lane], sm[1][lane]), fmaxf(sm[2][lane], sm[3][lane]));
+  float M = sm[0][lane];
+#pragma unroll
+  for (int w = 1; w < CSM_W; ++w) M = fmaxf(M, sm[w][lane]);
   float Lsum = 0.f;
 #pragma unroll
-  for (int w = 0; w < 4; ++w)
+  for (int w = 0; w < CSM_W; ++w)
     if (ss[w][lane] > 0.f) Lsum += ss[w][lane] * __expf(sm[w][lane] - M);
   if (j < S) {
     const float inv = 1.f / Lsum;
-    for (int i = wave; i < S; i += 4) pb[(long long)i * ldp + j] = f2bf(__expf(base[(long long)i * lds + j] - M) * inv);
+    int i = wave;
+    for (; i + 3 * CSM_W < S; i += 4 * CSM_W) {
+      const float v0 = base[(long long)i * lds + j], v1 = base[(long long)(i + CSM_W) * lds + j];
+      const float v2 = base[(long long)(i + 2 * CSM_W) * lds + j], v3 = base[(long long)(i + 3 * CSM_W) * lds + j];
+      pb[(long long)i * ldp + j] = f2bf(__expf(v0 - M) * inv);
+      pb[(long long)(i + CSM_W) * ldp + j] = f2bf(__expf(v1 - M) * inv);
+      pb[(long long)(i + 2 * CSM_W) * ldp + j] = f2bf(__expf(v2 - M) * inv);
+      pb[(long long)(i + 3 * CSM_W) * ldp + j] = f2bf(__expf(v3 - M) * inv);
+    }
+    for (; i < S; i += CSM_W) pb[(long long)i * ldp + j] = f2bf(__expf(base[(long long)i * lds + j] - M) * inv);
   } else if (j < ldp) {
-    for (int i = wave; i < S; i += 4) pb[(long long)i * ldp + j] = 0;
+    for (int i = wave; i < S; i += CSM_W) pb[(long long)i * ldp + j] = 0;
   }
 }
 
 extern "C" int sdm_col_softmax_bf16(const float* scores, uint16_t* P, int batch, int S, int64_t lds, int64_t ldp,
                                     sdm_stream_t s) {
   SDM_CHECK_ARG(scores && P && batch > 0 && S > 0 && lds >= S && ldp >= S, "col_softmax_bf16: bad args");
-  hipLaunchKernelGGL(col_softmax_bf16_kernel, dim3(cdiv(ldp, 64), batch), dim3(256), 0, (hipStream_t)s, scores, P, S,
+  hipLaunchKernelGGL(col_softmax_bf16_kernel, dim3(cdiv(ldp, 64), batch), dim3(64 * CSM_W), 0, (hipStream_t)s, scores, P, S,
                      (long long)lds, (long long)ldp);
   SDM_CHECK_LAUNCH("col_softmax_bf16");
   return SDM_OK;
@@ -1043,5 +1108,58 @@ extern "C" int sdm_gn_apply_fused_bf16(const void* src, int64_t ld_src, int src_
                      (long long)ld_src, src_raw, alpha, bias, act, HW, C, groups, eps, gamma, beta, mod, mod_nstride,
                      (const bf16_t*)x0, (long long)ldx0, (const bf16_t*)x1, (long long)ldx1, csplit, (bf16_t*)out, (long long)ldo);
   SDM_CHECK_LAUNCH("gn_apply_fused_bf16");
+  return SDM_OK;
+}
+
+
+// --------------------------------------------------------------------------------------------
+// GroupNorm fold from per-(image, channel) sums emitted by the producing conv's epilogue (sdm_igemm_bf16 with gn_sums):
+// the statistics need no pass over the activation any more.  One wave per (image, group); clears the sums it consumed
+// (zero-filled contract, like the split-K scratch).  Same tables as sdm_gn_affine.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void gn_finalize_kernel(float* __restrict__ sums, int HW, int C, int groups, float eps,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ mod, int mod_ns, float* __restrict__ scale,
+                                                         float* __restrict__ shift, float* __restrict__ mean_o,
+                                                         float* __restrict__ rstd_o) {
+  const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cpg = C / groups;
+  double s1 = 0.0, s2 = 0.0;
+  for (int c = threadIdx.x; c < cpg; c += 64) {
+    float* p = sums + ((long long)n * C + g * cpg + c) * 2;
+    s1 += p[0];
+    s2 += p[1];
+    p[0] = 0.f;
+    p[1] = 0.f;
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  const double total = (double)HW * cpg;
+  const double mean = s1 / total;
+  double var = s2 / total - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float mu = (float)mean;
+  if (threadIdx.x == 0 && mean_o) {
+    mean_o[n * groups + g] = mu;
+    rstd_o[n * groups + g] = rstd;
+  }
+  for (int c = threadIdx.x; c < cpg; c += 64) {
+    const int ch = g * cpg + c;
+    const float ga = gamma[ch], be = beta[ch];
+    const float sm = mod ? mod[(long long)n * mod_ns + ch] : 1.f;
+    scale[(long long)n * C + ch] = rstd * ga * sm;
+    shift[(long long)n * C + ch] = mod ? (be - mu * rstd * ga) * sm + sm : (be - mu * rstd * ga);
+  }
+}
+
+extern "C" int sdm_gn_finalize(float* sums, int images, int HW, int C, int groups, float eps, const float* gamma,
+                               const float* beta, const float* mod, int mod_nstride, float* scale, float* shift, float* mean,
+                               float* rstd, sdm_stream_t s) {
+  SDM_CHECK_ARG(sums && gamma && beta && scale && shift && (mean == nullptr) == (rstd == nullptr), "gn_finalize: null pointer");
+  SDM_CHECK_ARG(images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_finalize: C %d not divisible by groups %d", C, groups);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(images * groups), dim3(64), 0, (hipStream_t)s, sums, HW, C, groups, eps, gamma,
+                     beta, mod, mod_nstride, scale, shift, mean, rstd);
+  SDM_CHECK_LAUNCH("gn_finalize");
   return SDM_OK;
 }

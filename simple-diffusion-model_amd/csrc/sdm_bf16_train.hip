@@ -544,33 +544,46 @@ extern "C" int sdm_gn_adagn_bwd_bf16(const uint16_t* dout, int64_t lddo, const u
 // column-softmax backward: dS[i][j] = scale * P[i][j] * (dP[i][j] - sum_i P[i][j] dP[i][j]);  P bf16, dP fp32 -> dS bf16;
 // dS columns [S, ldds) are zero-filled (reduction padding of the contractions that follow).
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void col_softmax_bwd_bf16_kernel(const bf16_t* __restrict__ p, long long ldp,
-                                                                   const float* __restrict__ dp, long long lddp,
-                                                                   bf16_t* __restrict__ ds, long long ldds, int S, float scale) {
-  __shared__ float sd[4][64];
+#define CSB_W 16   // row phases (waves) per workgroup, lane = column (see col_softmax_bf16_kernel)
+__global__ __launch_bounds__(64 * CSB_W) void col_softmax_bwd_bf16_kernel(const bf16_t* __restrict__ p, long long ldp,
+                                                                          const float* __restrict__ dp, long long lddp,
+                                                                          bf16_t* __restrict__ ds, long long ldds, int S,
+                                                                          float scale) {
+  __shared__ float sd[CSB_W][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + lane;
   const bf16_t* pb = p + (long long)blockIdx.y * S * ldp;
   const float* dpb = dp + (long long)blockIdx.y * S * lddp;
   bf16_t* dsb = ds + (long long)blockIdx.y * S * ldds;
-  float dot = 0.f;
-  if (j < S)
-    for (int i = wave; i < S; i += 4) dot = fmaf(bf2f(pb[(long long)i * ldp + j]), dpb[(long long)i * lddp + j], dot);
-  sd[wave][lane] = dot;
-  __syncthreads();
-  dot = sd[0][lane] + sd[1][lane] + sd[2][lane] + sd[3][lane];
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
   if (j < S) {
-    for (int i = wave; i < S; i += 4)
+    int i = wave;
+    for (; i + 3 * CSB_W < S; i += 4 * CSB_W) {       // four independent rows per trip
+      d0 = fmaf(bf2f(pb[(long long)i * ldp + j]), dpb[(long long)i * lddp + j], d0);
+      d1 = fmaf(bf2f(pb[(long long)(i + CSB_W) * ldp + j]), dpb[(long long)(i + CSB_W) * lddp + j], d1);
+      d2 = fmaf(bf2f(pb[(long long)(i + 2 * CSB_W) * ldp + j]), dpb[(long long)(i + 2 * CSB_W) * lddp + j], d2);
+      d3 = fmaf(bf2f(pb[(long long)(i + 3 * CSB_W) * ldp + j]), dpb[(long long)(i + 3 * CSB_W) * lddp + j], d3);
+    }
+    for (; i < S; i += CSB_W) d0 = fmaf(bf2f(pb[(long long)i * ldp + j]), dpb[(long long)i * lddp + j], d0);
+  }
+  sd[wave][lane] = (d0 + d1) + (d2 + d3);
+  __syncthreads();
+  float dot = 0.f;
+#pragma unroll
+  for (int w = 0; w < CSB_W; ++w) dot += sd[w][lane];
+  if (j < S) {
+#pragma unroll 4
+    for (int i = wave; i < S; i += CSB_W)
       dsb[(long long)i * ldds + j] = f2bf(scale * bf2f(pb[(long long)i * ldp + j]) * (dpb[(long long)i * lddp + j] - dot));
   } else if (j < ldds) {
-    for (int i = wave; i < S; i += 4) dsb[(long long)i * ldds + j] = 0;
+    for (int i = wave; i < S; i += CSB_W) dsb[(long long)i * ldds + j] = 0;
   }
 }
 
 extern "C" int sdm_col_softmax_bwd_bf16(const uint16_t* P, int64_t ldp, const float* dP, int64_t lddp, uint16_t* dS,
                                         int64_t ldds, int batch, int S, float scale, sdm_stream_t s) {
   SDM_CHECK_ARG(P && dP && dS && batch > 0 && S > 0 && ldp >= S && lddp >= S && ldds >= S, "col_softmax_bwd_bf16: bad args");
-  hipLaunchKernelGGL(col_softmax_bwd_bf16_kernel, dim3(cdiv(ldds, 64), batch), dim3(256), 0, (hipStream_t)s, P, (long long)ldp,
+  hipLaunchKernelGGL(col_softmax_bwd_bf16_kernel, dim3(cdiv(ldds, 64), batch), dim3(64 * CSB_W), 0, (hipStream_t)s, P, (long long)ldp,
                      dP, (long long)lddp, dS, (long long)ldds, S, scale);
   SDM_CHECK_LAUNCH("col_softmax_bwd_bf16");
   return SDM_OK;

@@ -694,14 +694,16 @@ extern "C" int sdm_gn_adagn_bwd(const float* dout, int64_t lddo, const float* y,
 // --------------------------------------------------------------------------------------------
 // column softmax: normalise over rows i for every column j.  Block = 64 columns x 4 row-phases.
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void col_softmax_kernel(float* __restrict__ sc, int S, long long lds) {
-  __shared__ float sm[4][64], ss[4][64];
+#define CS_W 16   // row phases (waves) per workgroup; lane = column.  16 phases keep enough loads in flight (the 4-phase form
+                  // streamed the S=4096 score matrices at 1.3 TB/s)
+__global__ __launch_bounds__(64 * CS_W) void col_softmax_kernel(float* __restrict__ sc, int S, long long lds) {
+  __shared__ float sm[CS_W][64], ss[CS_W][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + lane;
   float* base = sc + (long long)blockIdx.y * S * lds;
   float m = -INFINITY, l = 0.f;
   if (j < S) {
-    for (int i = wave; i < S; i += 4) {
+    for (int i = wave; i < S; i += CS_W) {
       const float v = base[(long long)i * lds + j];
       if (v > m) {
         l = l * __expf(m - v) + 1.f;
@@ -714,14 +716,17 @@ __global__ __launch_bounds__(256) void col_softmax_kernel(float* __restrict__ sc
   sm[wave][lane] = m;
   ss[wave][lane] = l;
   __syncthreads();
-  float M = fmaxf(fmaxf(sm[0][lane], sm[1][lane]), fmaxf(sm[2][lane], sm[3][lane]));
+  float M = sm[0][lane];
+#pragma unroll
+  for (int w = 1; w < CS_W; ++w) M = fmaxf(M, sm[w][lane]);
   float Lsum = 0.f;
 #pragma unroll
-  for (int w = 0; w < 4; ++w)
+  for (int w = 0; w < CS_W; ++w)
     if (ss[w][lane] > 0.f) Lsum += ss[w][lane] * __expf(sm[w][lane] - M);
   if (j < S) {
     const float inv = 1.f / Lsum;
-    for (int i = wave; i < S; i += 4) {
+#pragma unroll 4
+    for (int i = wave; i < S; i += CS_W) {
       float* p = base + (long long)i * lds + j;
       *p = __expf(*p - M) * inv;
     }
@@ -730,25 +735,30 @@ __global__ __launch_bounds__(256) void col_softmax_kernel(float* __restrict__ sc
 
 extern "C" int sdm_col_softmax(float* scores, int batch, int S, int64_t lds, sdm_stream_t s) {
   SDM_CHECK_ARG(scores && batch > 0 && S > 0 && lds >= S, "col_softmax: bad args");
-  hipLaunchKernelGGL(col_softmax_kernel, dim3(cdiv(S, 64), batch), dim3(256), 0, (hipStream_t)s, scores, S, (long long)lds);
+  hipLaunchKernelGGL(col_softmax_kernel, dim3(cdiv(S, 64), batch), dim3(64 * CS_W), 0, (hipStream_t)s, scores, S, (long long)lds);
   SDM_CHECK_LAUNCH("col_softmax");
   return SDM_OK;
 }
 
-__global__ __launch_bounds__(256) void col_softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, int S,
-                                                              long long lds, float scale) {
-  __shared__ float sd[4][64];
+__global__ __launch_bounds__(64 * CS_W) void col_softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, int S,
+                                                                    long long lds, float scale) {
+  __shared__ float sd[CS_W][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + lane;
   const long long bo = (long long)blockIdx.y * S * lds;
   float dot = 0.f;
-  if (j < S)
-    for (int i = wave; i < S; i += 4) dot = fmaf(p[bo + (long long)i * lds + j], dp[bo + (long long)i * lds + j], dot);
+  if (j < S) {
+#pragma unroll 4
+    for (int i = wave; i < S; i += CS_W) dot = fmaf(p[bo + (long long)i * lds + j], dp[bo + (long long)i * lds + j], dot);
+  }
   sd[wave][lane] = dot;
   __syncthreads();
-  dot = sd[0][lane] + sd[1][lane] + sd[2][lane] + sd[3][lane];
+  dot = 0.f;
+#pragma unroll
+  for (int w = 0; w < CS_W; ++w) dot += sd[w][lane];
   if (j < S)
-    for (int i = wave; i < S; i += 4) {
+#pragma unroll 4
+    for (int i = wave; i < S; i += CS_W) {
       const long long o = bo + (long long)i * lds + j;
       dp[o] = scale * p[o] * (dp[o] - dot);
     }
@@ -756,7 +766,7 @@ __global__ __launch_bounds__(256) void col_softmax_bwd_kernel(const float* __res
 
 extern "C" int sdm_col_softmax_bwd(const float* p, float* dp, int batch, int S, int64_t lds, float scale, sdm_stream_t s) {
   SDM_CHECK_ARG(p && dp && batch > 0 && S > 0 && lds >= S, "col_softmax_bwd: bad args");
-  hipLaunchKernelGGL(col_softmax_bwd_kernel, dim3(cdiv(S, 64), batch), dim3(256), 0, (hipStream_t)s, p, dp, S,
+  hipLaunchKernelGGL(col_softmax_bwd_kernel, dim3(cdiv(S, 64), batch), dim3(64 * CS_W), 0, (hipStream_t)s, p, dp, S,
                      (long long)lds, scale);
   SDM_CHECK_LAUNCH("col_softmax_bwd");
   return SDM_OK;

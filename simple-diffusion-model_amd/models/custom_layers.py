@@ -424,7 +424,9 @@ class UNet_ConvBlock(nn.Module):
     def run(self, ctx, x, emb=None):
         c = self.conv_layer.conv
         act = ACT_SILU if self.use_activation else ACT_NONE
-        y = ops.conv_fwd(x, c.taps_for(ctx), c.bias, "c3s1", act, save_z=ctx.train and self.use_activation)
+        has_gn = emb is not None and hasattr(self, "adagn")
+        y = ops.conv_fwd(x, c.taps_for(ctx), c.bias, "c3s1", act, save_z=ctx.train and self.use_activation,
+                         gn_stats=has_gn and ctx.bf16)
         if emb is None or not hasattr(self, "adagn"):
             if ctx.train:
                 ctx.rec[self] = (x, y, None, None, None)

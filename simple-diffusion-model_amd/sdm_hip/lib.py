@@ -38,7 +38,7 @@ class IgemmDesc(C.Structure):
         ("res", fp), ("ldres", C.c_int64), ("r_bs0", C.c_int64), ("r_bs1", C.c_int64),
         ("res2", fp), ("ldres2", C.c_int64),
         ("dact_z", fp), ("ldz", C.c_int64), ("dact_ncols", C.c_int),
-        ("ws", fp), ("ws_bytes", C.c_size_t), ("defer_epilogue", C.c_int),
+        ("ws", fp), ("ws_bytes", C.c_size_t), ("gn_sums", fp), ("defer_epilogue", C.c_int),
     ]
 
 
@@ -132,6 +132,7 @@ _PROTOS = {
     "sdm_affine_residual_bf16": (_i, [fp, _i64, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, _i, _i, _i, fp]),
     "sdm_col_softmax_bf16": (_i, [fp, fp, _i, _i, _i64, _i64, fp]),
     "sdm_gn_apply_fused_bf16": (_i, [fp, _i64, _i, _f, fp, _i, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, fp]),
+    "sdm_gn_finalize": (_i, [fp, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, fp, fp, fp, fp]),
     "sdm_rows_to_nchw": (_i, [fp, _i64, fp, _i, _i, _i, _i, fp]),
     "sdm_transpose_bf16": (_i, [fp, _i64, _i64, _i64, _i, fp, _i64, _i64, _i, _i, _i, fp]),
     # bf16 training path
@@ -162,6 +163,7 @@ def last_error():
     return _lib.sdm_last_error().decode()
 
 
+STATS_DONE = 2    # sdm_igemm_bf16(gn_sums=...) accumulated the GroupNorm statistics in its epilogue
 DEFERRED = 1      # sdm_igemm(defer_epilogue=1) left raw split-K sums for the caller's next kernel to finish
 
 

@@ -49,11 +49,12 @@ class Act:
     """An activation as pixel rows: ``t`` is [n*h*w, c] (row pitch t.stride(0)); ``t2`` an optional second
     tensor concatenated on channels; ``scale``/``shift`` an optional pending per-(image,channel) affine
     (deferred GroupNorm+AdaGN).  ``z`` is the pre-activation kept for backward when training."""
-    __slots__ = ("t", "n", "h", "w", "t2", "scale", "shift", "z")
+    __slots__ = ("t", "n", "h", "w", "t2", "scale", "shift", "z", "stats")
 
     def __init__(self, t, n, h, w, t2=None, scale=None, shift=None, z=None):
         self.t, self.n, self.h, self.w, self.t2 = t, n, h, w, t2
         self.scale, self.shift, self.z = scale, shift, z
+        self.stats = None       # [n, c, 2] {sum, sum of squares} per (image, channel) when the producing conv emitted them
 
     @property
     def c1(self):
@@ -188,6 +189,8 @@ class _Workspace:
 
 WS = _Workspace()
 GNWS = _Workspace()     # scratch of sdm_gn_adagn_bwd (same zero-filled contract; separate so sizes do not interact)
+GNSUMS = _Workspace()   # per-(image, channel) GroupNorm sums a bf16 conv epilogue emits; sdm_gn_finalize leaves them zero
+CONV_GN_STATS = [True]  # bf16 rows: GroupNorm statistics in the producing conv's epilogue (False: separate pass)
 
 # ---- tap tables -----------------------------------------------------------------------------
 _C3 = [(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
@@ -301,7 +304,7 @@ def conv_out_hw(h, w, kind):
     raise ValueError(kind)
 
 
-def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False, defer=False):
+def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False, defer=False, gn_stats=False):
     """x: Act; wt: [taps, c_out, c_in] contiguous view; returns Act (plain).  ``defer`` (fp32, no save_z): if the library
     splits K it skips its finishing pass and a Deferred is returned instead (see gn_apply_fused)."""
     T, cout, cin = wt.shape
@@ -332,9 +335,17 @@ def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False, defer=False):
     d.out, d.ldo = _p(out), out.stride(0)
     d.bias, d.act, d.out_preact = _p(bias), act, _p(z)
     d.defer_epilogue = int(bool(defer) and not save_z)
-    if _launch_igemm(d, wt.device, bf16=bf) == lib.DEFERRED:
+    sums = None
+    if gn_stats and bf and CONV_GN_STATS[0] and kind == "c3s1":
+        sums = GNSUMS.get(x.n * cout * 2 * 4, wt.device)       # zero-filled; consumed (and cleared) by sdm_gn_finalize
+        d.gn_sums = _p(sums)
+    rc = _launch_igemm(d, wt.device, bf16=bf)
+    if rc == lib.DEFERRED:
         return Deferred(WS.buf, x.n, ho, wo, cout, bias, act, BF16 if bf else torch.float32)
-    return Act(out, x.n, ho, wo, z=z)
+    y = Act(out, x.n, ho, wo, z=z)
+    if rc == lib.STATS_DONE:
+        y.stats = sums
+    return y
 
 
 def conv_dgrad(g, g_hw, wt, kind, x_hw, n, res=None, res2=None, dact_z=None, dact_ncols=0, out=None):
@@ -761,6 +772,11 @@ def gn_affine(y, gamma, beta, mod, groups=32, eps=1e-5, want_stats=True):
     if y.t.dtype == BF16:
         mean = torch.empty((y.n, groups), dtype=torch.float32, device=dev) if want_stats else None
         rstd = torch.empty_like(mean) if want_stats else None
+        if y.stats is not None:        # the producing conv's epilogue already summed the statistics: no pass over y
+            lib.call("sdm_gn_finalize", _p(y.stats), y.n, y.h * y.w, C_, groups, eps, _p(gamma), _p(beta), _p(mod), mns,
+                     _p(scale), _p(shift), _p(mean), _p(rstd), _stream())
+            y.stats = None
+            return scale, shift, mean, rstd
         lib.call("sdm_gn_affine_bf16", _p(y.t), y.t.stride(0), y.n, y.h * y.w, C_, groups, eps, _p(gamma), _p(beta), _p(mod),
                  mns, _p(scale), _p(shift), _p(mean), _p(rstd), _stream())
         return scale, shift, mean, rstd

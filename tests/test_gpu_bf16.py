@@ -276,3 +276,29 @@ def test_residual_block_fused_tail_bf16(dev, n, c, h, w):
     assert rel(fused, plain) < 4e-3, rel(fused, plain)
     assert rel(fused, ref32) < 1e-2, rel(fused, ref32)
     assert ops.WS.buf is None or float(ops.WS.buf.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 128, 16, 16), (3, 64, 8, 16), (2, 256, 16, 8), (1, 128, 12, 12)])
+def test_groupnorm_statistics_from_the_conv_epilogue(dev, n, c, h, w):
+    """sdm_igemm_bf16 with gn_sums: per-(image, channel) sum / sum of squares of the stored outputs from the conv's epilogue
+    and sdm_gn_finalize, against the separate statistics pass (sdm_gn_affine_bf16) on the same conv output; shapes where the
+    library emits them (tiles inside one image) and where it declines (12x12 = 144 pixels is no multiple of the tile rows)."""
+    from models import custom_layers as L
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(n + c + h * w)
+    conv = L.TapConv(c, c, "c3s1").to(dev)
+    ctx = L.RunCtx(True, bf16=True)
+    x = ops.Act(torch.randn(n * h * w, c, generator=g).cuda().to(torch.bfloat16), n, h, w)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda()
+    mod = torch.randn(n, c, generator=g).cuda()
+    ops.CONV_GN_STATS[0] = True
+    y = ops.conv_fwd(x, conv.taps_for(ctx), conv.bias, "c3s1", ops.ACT_SILU, save_z=True, gn_stats=True)
+    emitted = y.stats is not None
+    assert emitted == ((h * w) % 64 == 0 and n * h * w >= 64)
+    s1, h1, m1, r1 = ops.gn_affine(y, gamma, beta, mod, want_stats=True)
+    assert y.stats is None
+    y2 = ops.Act(y.t, n, h, w)
+    s0, h0, m0, r0 = ops.gn_affine(y2, gamma, beta, mod, want_stats=True)
+    for a, b in ((s1, s0), (h1, h0), (m1, m0), (r1, r0)):
+        assert rel(a, b) < 2e-5, rel(a, b)
+    assert ops.GNSUMS.buf is None or float(ops.GNSUMS.buf.abs().max()) == 0.0
