@@ -278,11 +278,13 @@ def test_residual_block_fused_tail_bf16(dev, n, c, h, w):
     assert ops.WS.buf is None or float(ops.WS.buf.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("n,c,h,w", [(2, 128, 16, 16), (3, 64, 8, 16), (2, 256, 16, 8), (1, 128, 12, 12)])
-def test_groupnorm_statistics_from_the_conv_epilogue(dev, n, c, h, w):
+@pytest.mark.parametrize("n,c,h,w,expect", [(10, 128, 64, 64, True), (24, 256, 32, 32, True), (2, 128, 16, 16, None),
+                                            (3, 64, 8, 16, None), (1, 128, 12, 12, False)])
+def test_groupnorm_statistics_from_the_conv_epilogue(dev, n, c, h, w, expect):
     """sdm_igemm_bf16 with gn_sums: per-(image, channel) sum / sum of squares of the stored outputs from the conv's epilogue
     and sdm_gn_finalize, against the separate statistics pass (sdm_gn_affine_bf16) on the same conv output; shapes where the
-    library emits them (tiles inside one image) and where it declines (12x12 = 144 pixels is no multiple of the tile rows)."""
+    library emits them (large unsplit convs, tiles inside one image), where it may split K instead (small ones: either way
+    the tables agree) and where it must decline (12x12 = 144 pixels is no multiple of the tile rows)."""
     from models import custom_layers as L
     from sdm_hip import ops
     g = torch.Generator().manual_seed(n + c + h * w)
@@ -294,7 +296,7 @@ def test_groupnorm_statistics_from_the_conv_epilogue(dev, n, c, h, w):
     ops.CONV_GN_STATS[0] = True
     y = ops.conv_fwd(x, conv.taps_for(ctx), conv.bias, "c3s1", ops.ACT_SILU, save_z=True, gn_stats=True)
     emitted = y.stats is not None
-    assert emitted == ((h * w) % 64 == 0 and n * h * w >= 64)
+    assert expect is None or emitted == expect
     s1, h1, m1, r1 = ops.gn_affine(y, gamma, beta, mod, want_stats=True)
     assert y.stats is None
     y2 = ops.Act(y.t, n, h, w)
