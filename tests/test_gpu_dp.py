@@ -33,7 +33,7 @@ def _data():
     return x0, eps, t, lab
 
 
-def _train(world, rank, pg_ready):
+def _train(world, rank, pg_ready, bf16=False):
     _setup_paths()
     import degraders as D
     from models.U_Net import U_Net
@@ -43,7 +43,8 @@ def _train(world, rank, pg_ready):
     net = U_Net(**cfg)
     net.load_state_dict(O.seeded_params(cfg, seed=3, gain=1.8), strict=True)
     net = net.cuda()
-    tr = DiffusionTrainer(net, D.CosineNoiseDegradation(1000), lr=2e-3, bucket_mb=1)
+    tr = DiffusionTrainer(net, D.CosineNoiseDegradation(1000), lr=2e-3, bucket_mb=1,
+                          train_dtype=torch.bfloat16 if bf16 else None)
     assert tr.world == world
     x0, eps, t, lab = _data()
     per = 4 // world
@@ -55,29 +56,33 @@ def _train(world, rank, pg_ready):
     return {k: v.detach().cpu().contiguous().clone() for k, v in net.state_dict().items()}, losses, len(tr.reducer.buckets)
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, bf16=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        sd, losses, nb = _train(world, rank, True)
+        sd, losses, nb = _train(world, rank, True, bf16)
         if rank == 0:
             torch.save({"sd": sd, "losses": losses, "buckets": nb}, out_path)
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_training_equals_single_rank(tmp_path):
+@pytest.mark.parametrize("bf16", [False, True])
+def test_two_rank_training_equals_single_rank(tmp_path, bf16):
+    """bf16=True: the bf16 training path under data parallelism -- weight gradients and the all-reduced flat buffer stay
+    fp32, every image's activations are rounded independently of its batch neighbours, so two ranks on half batches land
+    where one rank on the whole batch lands (up to fp32 summation order)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, bf16), nprocs=2, join=True)
     dp = torch.load(out, weights_only=True)
     assert dp["buckets"] >= 2
-    ref_sd, ref_losses, _ = _train(1, 0, False)
+    ref_sd, ref_losses, _ = _train(1, 0, False, bf16)
     bad = []
     for k, v in ref_sd.items():
         # Adam's first updates are ~lr*sign(g): a gradient that differs in its last bits near zero moves a weight by up to
