@@ -274,68 +274,76 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
     // Staged through LDS: the accumulator layout gives a lane ONE column and 16 scattered rows of a 32x32 tile, i.e.
     // 2-byte stores; the ring (no longer needed) is reused as an fp32 [BM][BN] tile so that every lane finishes 4
     // consecutive columns and stores 8 bytes (16 for fp32 scores), rows fully coalesced.
-    static_assert((size_t)BM * BN <= (size_t)NBUF * (BM + BN) * ROWF, "output tile must fit in the ring");
-    __syncthreads();                       // every wave is done with the last K-step's fragments
+    // A tile larger than the ring (256x256) is staged in SL row slabs, each the i-th 32-row blocks of every wave row.
+    constexpr int SL = ((size_t)BM * BN <= (size_t)NBUF * (BM + BN) * ROWF) ? 1 : ((size_t)BM * BN / 2 <= (size_t)NBUF * (BM + BN) * ROWF ? 2 : TM);
+    constexpr int TMS = TM / SL;             // 32-row blocks per wave and slab
+    static_assert(TM % SL == 0 && (size_t)(BM / SL) * BN <= (size_t)NBUF * (BM + BN) * ROWF, "output slab must fit in the ring");
     float* Ct = smem;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          Ct[row * BN + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];
-        }
-    __syncthreads();
     constexpr int C4 = BN / 4;
+    static_assert(NT % C4 == 0, "a thread keeps one column quad across its rows");
     f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};     // GroupNorm statistics of this thread's 4 columns
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      __syncthreads();                       // every wave is done with the last K-step's fragments / the previous slab
+#pragma unroll
+      for (int ii = 0; ii < TMS; ++ii)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int prow = wm * TMS * 32 + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            Ct[prow * BN + wn * TN * 32 + j * 32 + l31] = acc[sl * TMS + ii][j][r];
+          }
+      __syncthreads();
 #pragma unroll 2
-    for (int e = tid; e < BM * C4; e += NT) {
-      const int row = e / C4, c4 = (e - row * C4) * 4;
-      const int col = n0 + c4;
-      const long long orow = s_orow[row];
-      if (orow < 0 || col >= N) continue;
-      f32x4 v = *(const f32x4*)(Ct + row * BN + c4);
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (d.bias) bv = *(const f32x4*)(d.bias + col);
+      for (int e = tid; e < (BM / SL) * C4; e += NT) {
+        const int prow = e / C4, c4 = (e - prow * C4) * 4;
+        const int row = SL == 1 ? prow : (prow / (TMS * 32)) * (TM * 32) + sl * (TMS * 32) + prow % (TMS * 32);
+        const int col = n0 + c4;
+        const long long orow = s_orow[row];
+        if (orow < 0 || col >= N) continue;
+        f32x4 v = *(const f32x4*)(Ct + prow * BN + c4);
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (d.bias) bv = *(const f32x4*)(d.bias + col);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = v[q] * d.alpha + bv[q];
-      if (pre16) {     // pre-activation copy for the backward (training)
-        u16x4 zo;
+        for (int q = 0; q < 4; ++q) v[q] = v[q] * d.alpha + bv[q];
+        if (pre16) {     // pre-activation copy for the backward (training)
+          u16x4 zo;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) zo[q] = f2bf(v[q]);
-        *(u16x4*)(pre16 + obo + orow * d.ldo + col) = zo;
-      }
+          for (int q = 0; q < 4; ++q) zo[q] = f2bf(v[q]);
+          *(u16x4*)(pre16 + obo + orow * d.ldo + col) = zo;
+        }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = sdm_act(v[q], d.act);
-      if (res16) {
-        const u16x4 rv = *(const u16x4*)(res16 + rbo + orow * d.ldres + col);
+        for (int q = 0; q < 4; ++q) v[q] = sdm_act(v[q], d.act);
+        if (res16) {
+          const u16x4 rv = *(const u16x4*)(res16 + rbo + orow * d.ldres + col);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += bf2f(rv[q]);
-      }
-      if (res216) {
-        const u16x4 rv = *(const u16x4*)(res216 + orow * d.ldres2 + col);
+          for (int q = 0; q < 4; ++q) v[q] += bf2f(rv[q]);
+        }
+        if (res216) {
+          const u16x4 rv = *(const u16x4*)(res216 + orow * d.ldres2 + col);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += bf2f(rv[q]);
-      }
-      if (dz16 && (d.dact_ncols == 0 || col < d.dact_ncols)) {   // data gradient: times silu'(z) of the producer
-        const u16x4 zv = *(const u16x4*)(dz16 + orow * d.ldz + col);
+          for (int q = 0; q < 4; ++q) v[q] += bf2f(rv[q]);
+        }
+        if (dz16 && (d.dact_ncols == 0 || col < d.dact_ncols)) {   // data gradient: times silu'(z) of the producer
+          const u16x4 zv = *(const u16x4*)(dz16 + orow * d.ldz + col);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] *= sdm_dsilu(bf2f(zv[q]));
-      }
-      if (L.out_f32) {
-        *(f32x4*)(d.out + obo + orow * d.ldo + col) = v;
-      } else {
-        u16x4 o;
+          for (int q = 0; q < 4; ++q) v[q] *= sdm_dsilu(bf2f(zv[q]));
+        }
+        if (L.out_f32) {
+          *(f32x4*)(d.out + obo + orow * d.ldo + col) = v;
+        } else {
+          u16x4 o;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = f2bf(v[q]);
-        *(u16x4*)(out16 + obo + orow * d.ldo + col) = o;
-        if (L.gn_stats) {       // statistics of the values the next layer will read (after rounding to bf16)
+          for (int q = 0; q < 4; ++q) o[q] = f2bf(v[q]);
+          *(u16x4*)(out16 + obo + orow * d.ldo + col) = o;
+          if (L.gn_stats) {       // statistics of the values the next layer will read (after rounding to bf16)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float r = bf2f(o[q]);
-            gs[q] += r;
-            gq[q] = fmaf(r, r, gq[q]);
+            for (int q = 0; q < 4; ++q) {
+              const float r = bf2f(o[q]);
+              gs[q] += r;
+              gq[q] = fmaf(r, r, gq[q]);
+            }
           }
         }
       }
@@ -366,6 +374,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
     }
     return;
   }
+  if constexpr (BM > 128) return;     // the large tiles are only planned with the vector epilogue and without split-K
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -445,17 +454,20 @@ static int bf_validate(const sdm_igemm_desc* d, int out_f32) {
   return SDM_OK;
 }
 
-// Tile configurations.  Measured on MI355X (profiles/r01_bf16_probe.txt): the contraction saturates at 800-900 TFLOP/s
-// -- operand movement L2 -> LDS (64 flop per tile byte at 128x128) and LDS fragment reads (one ds_read_b128 per
-// MFMA) run close to their limits together -- and what matters most below that is co-residency: two workgroups per CU
-// hide each other's DMA latency (ring 2, 64 KB: 1.3-1.5x over ring 3 with one workgroup).  A 256x128 / 8-wave tile
-// measured the same as two 128x128 workgroups, so it is not instantiated.
+// Tile configurations.  Measured on MI355X (profiles/r01_bf16_probe.txt, profiles/r02_bf16_tiles.txt): operand movement
+// L2 -> LDS (64 flop per tile byte at 128x128, 128 at 256x256) and LDS fragment reads (one ds_read_b128 per MFMA at a
+// 64x64 wave tile, 0.75 at 128x64) set the pace, not the matrix pipe, and every wave needs a partner on its SIMD to hide
+// DMA latency and barriers (one wave per SIMD -- 4-wave 256x128 / 256x256 tiles, or ring 3 with one workgroup -- measured
+// 0.7-0.9x of the configurations below).
 //   cfg 0: 128x128, 4 waves (2x2), ring 2 (64 KB): two workgroups per CU
 //   cfg 1:  64x64,  4 waves (2x2), ring 3 (48 KB): three workgroups per CU; small problems, with split-K
+//   cfg 2: 256x256, 8 waves (2x4, wave tile 128x64), ring 2 (128 KB): one workgroup per CU, two waves per SIMD; 1.17x the
+//          rate of cfg 0 once a launch has >= 256 such tiles (721 -> 843 TFLOP/s at 512 channels, 630 -> 751 at 256)
+//   cfg 3: as cfg 2 with 4x2 waves (wave tile 64x128): same rate within noise, force override only
 struct BfCfg { int bm, bn; };
-static const BfCfg kBfCfgs[2] = {{128, 128}, {64, 64}};
+static const BfCfg kBfCfgs[4] = {{128, 128}, {64, 64}, {256, 256}, {256, 256}};
 
-static void bf_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* ws_need) {
+static void bf_plan(const sdm_igemm_desc* d, bool big_ok, int* cfg, int* splitk, size_t* ws_need) {
   static const char* force = getenv("SDM_BF16_FORCE");   // "cfg,splitk" tuning override
   const long ph = (long)d->nphase * d->batch;
   int maxtaps = 0;
@@ -465,6 +477,14 @@ static void bf_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* ws_n
   const long t64 = (long)cdiv(d->M, 64) * cdiv(d->N, 64) * ph;
   int c = t128 >= 320 ? 0 : 1, sk = 1;
   if (d->N <= 64) c = 1;     // the 3-channel head conv: a 128-wide tile would be 98 % padding, a 64-wide one 95 %
+  if (c == 0 && big_ok) {
+    // rounds of resident workgroups (512 slots of 128x128, 256 of 256x256); a 256x256 tile is 4 tile units at 1.17x the
+    // rate of a co-resident pair: 4 / (2 * 1.17) = 1.71 rounds of cfg 0
+    static const char* nobig = getenv("SDM_BF16_BIG");
+    const long t256 = (long)cdiv(d->M, 256) * cdiv(d->N, 256) * ph;
+    const double cost128 = (double)cdiv(t128, 512), cost256 = 1.71 * (double)cdiv(t256, 256);
+    if (cost256 < cost128 && !(nobig && nobig[0] == '0')) c = 2;
+  }
   if (c == 1 && t64 < 512) {
     sk = (int)((512 + t64 - 1) / t64);
     if (sk > T / 4) sk = T / 4;
@@ -477,7 +497,7 @@ static void bf_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* ws_n
   if (d->batch > 1) sk = 1;
   if (force) {
     int fc = 0, fs = 1;
-    if (sscanf(force, "%d,%d", &fc, &fs) == 2 && fc >= 0 && fc <= 1) { c = fc; sk = fs < 1 ? 1 : (fs > T ? T : fs); }
+    if (sscanf(force, "%d,%d", &fc, &fs) == 2 && fc >= 0 && fc <= 3 && (fc < 2 || big_ok)) { c = fc; sk = fc >= 2 ? 1 : (fs < 1 ? 1 : (fs > T ? T : fs)); }
   }
   *cfg = c;
   *splitk = sk;
@@ -513,7 +533,7 @@ extern "C" size_t sdm_igemm_bf16_workspace_bytes(const sdm_igemm_desc* d) {
   if (bf_validate(d, 0) != SDM_OK) return 0;
   int b, sk;
   size_t need;
-  bf_plan(d, &b, &sk, &need);
+  bf_plan(d, false, &b, &sk, &need);     // an upper bound: the large tiles never split K
   return need;
 }
 
@@ -524,10 +544,6 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
   BfLaunch L;
   L.d = *d;
   L.out_f32 = out_f32 ? 1 : 0;
-  int cfg;
-  size_t need;
-  bf_plan(d, &cfg, &L.splitk, &need);
-  if (L.splitk > 1 && (d->ws == nullptr || d->ws_bytes < need)) L.splitk = 1;
   L.kchunks = cdiv(d->K, BKE);
   L.out_rows = (long long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
   {
@@ -542,6 +558,12 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
                 (d->dact_z == nullptr || (al(d->dact_z, 8) && d->ldz % 4 == 0 && d->dact_ncols % 4 == 0)) &&
                 !(noepi && noepi[0] == '0');
   }
+  static const char* nofast = getenv("SDM_BF16_FAST");
+  const bool fast = d->K % BKE == 0 && (d->a.p1 == nullptr || d->a.csplit % BKE == 0) && !(nofast && nofast[0] == '0');
+  int cfg;
+  size_t need;
+  bf_plan(d, fast && L.vec_epi, &cfg, &L.splitk, &need);
+  if (L.splitk > 1 && (d->ws == nullptr || d->ws_bytes < need)) L.splitk = 1;
   const int bm = kBfCfgs[cfg].bm, bn = kBfCfgs[cfg].bn;
   const int ntm = cdiv(d->M, bm);
   L.ntn = cdiv(d->N, bn);
@@ -558,10 +580,11 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
   L.gn_stats = d->gn_sums != nullptr && !out_f32 && L.vec_epi && L.splitk == 1 && d->batch == 1 && d->nphase == 1 &&
                d->ostride == 1 && d->sstride == 1 && d->Ht == d->Ho && d->Wt == d->Wo && d->N % 4 == 0 &&
                ((long)d->Ho * d->Wo) % kBfCfgs[cfg].bm == 0;
-  static const char* nofast = getenv("SDM_BF16_FAST");
-  const bool fast = d->K % BKE == 0 && (d->a.p1 == nullptr || d->a.csplit % BKE == 0) && !(nofast && nofast[0] == '0');
   if (cfg == 0) rc = fast ? launch_bf<128, 128, 2, 2, 2, true>(L, ntm, st) : launch_bf<128, 128, 2, 2, 2, false>(L, ntm, st);
-  else rc = fast ? launch_bf<64, 64, 2, 2, 3, true>(L, ntm, st) : launch_bf<64, 64, 2, 2, 3, false>(L, ntm, st);
+  else if (cfg == 1) rc = fast ? launch_bf<64, 64, 2, 2, 3, true>(L, ntm, st) : launch_bf<64, 64, 2, 2, 3, false>(L, ntm, st);
+  else if (cfg == 2 && fast && L.vec_epi && L.splitk == 1) rc = launch_bf<256, 256, 2, 4, 2, true>(L, ntm, st);
+  else if (cfg == 3 && fast && L.vec_epi && L.splitk == 1) rc = launch_bf<256, 256, 4, 2, 2, true>(L, ntm, st);
+  else rc = sdm_set_error(SDM_ERR_ARG, "igemm_bf16: tile configuration %d needs the FAST path, the vector epilogue and no split-K", cfg);
   if (rc != SDM_OK) return rc;
   if (L.splitk > 1 && d->defer_epilogue) return SDM_DEFERRED;   // raw fp32 sums stay in ws for sdm_gn_apply_fused_bf16
   if (L.gn_stats) return SDM_STATS_DONE;

@@ -55,13 +55,15 @@ struct WgradBfLaunch {
 // general walk (per-lane pixel coordinates with carries, two 64-bit multiplies per row) costs ~16 vector instructions per
 // matrix instruction and made the kernel issue-bound (profiles/r02_wgrad_bf16_512_pmc.json, round 2 first cut: 45 % of
 // wave time issuing, matrix pipe 20 % busy).
-template <int BT, int NBUF, bool FASTP>
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradBfLaunch L) {
+template <int BT, int WM, int WN, int NBUF, bool FASTP>
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(const WgradBfLaunch L) {
   const sdm_wgrad_desc& d = L.d;
-  constexpr int TM = BT / 64, TN = BT / 64;     // 32x32 MFMA tiles per wave (waves 2x2)
+  constexpr int NT = 64 * WM * WN;              // WM x WN waves, each owning (BT/WM) x (BT/WN)
+  constexpr int TM = BT / (32 * WM), TN = BT / (32 * WN);     // 32x32 MFMA tiles per wave
   constexpr int ROWB = 2 * BT;                  // bytes per LDS row
   constexpr int CPR = BT / 8;                   // 16-byte chunks per row
-  constexpr int RPP = 256 / CPR;                // pixel rows per DMA pass of the 256 threads
+  constexpr int RPP = NT / CPR;                 // pixel rows per DMA pass of the NT threads
+  static_assert(BKP % RPP == 0 && (RPP * ROWB) == (NT / 64) * 1024, "one DMA pass = one KiB per wave");
   constexpr int IT = BKP / RPP;                 // passes per operand per K-step
   constexpr int TILEB = BKP * ROWB;             // bytes per operand stage
   constexpr int G = 2 * IT;
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradBfLaunch L) 
   char* Bs = smem_wg + NBUF * TILEB;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN, h = lane >> 5;
   const int ntiles_ = gridDim.x / L.splitk;
   const int wg_ = xcd_contiguous_wg(blockIdx.x, gridDim.x);
   const int ks = wg_ / ntiles_, tile_ = wg_ - ks * ntiles_;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradBfLaunch L) 
   const int gdy = d.g_dy[tp], gdx = d.g_dx[tp], xdy = d.x_dy[tp], xdx = d.x_dx[tp];
   // DMA role of this thread: pixel rows (tid / CPR) + RPP*i, physical chunk slot tid % CPR -> logical chunk slot ^ f(row)
   const int drow = tid / CPR;
-  const int fk = BT == 128 ? ((drow & 3) << 2) : (((drow >> 1) & 1) << 2);
+  const int fk = BT >= 128 ? ((drow & 3) << 2) : (((drow >> 1) & 1) << 2);
   const int lchunk = (tid % CPR) ^ fk;
   const int cm = m0 + 8 * lchunk, cn = n0 + 8 * lchunk;
   const bool gch = cm < ((d.M + 7) & ~7), xch = cn < ((d.N + 7) & ~7);
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradBfLaunch L) 
 
   // transposing-read role of this lane (constant over K-steps): row q of its group's 4-row block, channel quad p
   const int i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, chalf = (lane >> 4) & 1;
-  const int fq = BT == 128 ? (q << 2) : ((q >> 1) << 2);
+  const int fq = BT >= 128 ? (q << 2) : ((q >> 1) << 2);
   int aoff[TM], boff[TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradBfLaunch L) 
       float a = 0.f;
 #pragma unroll 8
       for (int k = 0; k < BKP; ++k) {
-        const int f = BT == 128 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2);
+        const int f = BT >= 128 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2);
         a += bf2f(*(const bf16_t*)(Ab + k * ROWB + (((tid >> 3) ^ f) << 4) + ((tid & 7) << 1)));
       }
       bacc += a;
@@ -284,13 +286,13 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradBfLaunch L) 
     }
 }
 
-template <int BT, int NBUF, bool FASTP>
+template <int BT, int WM, int WN, int NBUF, bool FASTP>
 static int launch_wgrad_bf16(const WgradBfLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * NBUF * BKP * 2 * BT;
   dim3 grid(ntm * L.ntn * L.splitk, L.d.ntaps, L.d.batch);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_bf16_kernel<BT, NBUF, FASTP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)wgrad_bf16_kernel<BT, WM, WN, NBUF, FASTP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     attr_set = true;
   }
@@ -301,8 +303,8 @@ static int launch_wgrad_bf16(const WgradBfLaunch& L, int ntm, hipStream_t st) {
                    L.d.batch * (2.0 * (g_b + x_b) + 4.0 * w_b));
   }
   sdm_prof_pre(st);
-  hipLaunchKernelGGL((wgrad_bf16_kernel<BT, NBUF, FASTP>), grid, dim3(256), lds, st, L);
-  sdm_prof_post(st, BT == 128 ? 3 : 4, 2.0 * L.d.M * L.d.N * (double)L.d.images * L.d.Hk * L.d.Wk * L.d.ntaps * L.d.batch);
+  hipLaunchKernelGGL((wgrad_bf16_kernel<BT, WM, WN, NBUF, FASTP>), grid, dim3(64 * WM * WN), lds, st, L);
+  sdm_prof_post(st, BT >= 128 ? 3 : 4, 2.0 * L.d.M * L.d.N * (double)L.d.images * L.d.Hk * L.d.Wk * L.d.ntaps * L.d.batch);
   SDM_CHECK_LAUNCH("wgrad_bf16");
   return SDM_OK;
 }
@@ -344,33 +346,42 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
   // 128x128 tiles whenever the problem can feed them (the 64x64 form is LDS-read bound: 4 transposing reads per MFMA)
   const long blocks128 = (long)cdiv(d->M, 128) * cdiv(d->N, 128) * d->ntaps * d->batch;
   const bool big = d->M > 64 && d->N > 64 && (blocks128 >= 128 || (long)T * blocks128 >= 8L * 256);
-  const int bt = big ? 128 : 64;
-  const int ntm = cdiv(d->M, bt);
-  L.ntn = cdiv(d->N, bt);
-  const long blocks = (long)ntm * L.ntn * d->ntaps * d->batch;
-  // Split over pixels by a small cost model.  The grid is tiles x 9 taps x slices, which is rarely a multiple of the
-  // chip's resident-workgroup slots (2 per CU at 128x128, 3 at 64x64): 576 workgroups of a 1024x1024 layer run as one
-  // full wave plus a 12 %-full second one and took 1.78x the time of a balanced grid (profiles/r02_c5_bf16_launches).
-  // Cost of a choice = ceil(workgroups / slots) x K-steps per slice x step time + the fp32 atomics of the extra slices
-  // (~1.3 TB/s chip-wide, MI355X_MICROARCH.md) + a per-workgroup prologue/epilogue; step times calibrated on MI355X.
-  int sk = 1;
-  {
-    const double slots = big ? 512.0 : 768.0;
-    const double t_step = big ? 1.30e-6 : 0.70e-6;             // one K-step of a full wave of workgroups
-    const double out_bytes = (double)d->M * d->N * d->ntaps * d->batch * 4.0;
-    double best = 1e30;
-    for (int c = 1; c <= 128 && c <= (T >= 4 ? T / 4 : 1); ++c) {
-      const double waves = ceil((double)blocks * c / slots);
-      const double steps = ceil((double)T / c);
-      const double t = waves * (steps * t_step + 2.0e-6) + (c > 1 || d->accumulate == 1 ? out_bytes * c / 1.3e12 : out_bytes / 5e12);
-      if (t < best * 0.97) { best = t; sk = c; }               // prefer fewer slices unless it pays >= 3 %
-    }
-  }
+  // Tile and split over pixels by a small cost model.  The grid is tiles x 9 taps x slices, which is rarely a multiple of
+  // the chip's resident-workgroup slots (1 per CU at 256x256, 2 at 128x128, 3 at 64x64): 576 workgroups of a 1024x1024
+  // layer run as one full wave plus a 12 %-full second one and took 1.78x the time of a balanced grid
+  // (profiles/r02_c5_bf16_launches).  Cost of a choice = ceil(workgroups / slots) x K-steps per slice x step time + the
+  // fp32 atomics of the extra slices (~1.3 TB/s chip-wide, MI355X_MICROARCH.md) + a per-workgroup prologue/epilogue;
+  // step times calibrated on MI355X (a 256x256 / 8-wave workgroup does the work of four 128x128 ones per K-step).
   static const char* force = getenv("SDM_WGRAD_BF16_FORCE");   // "bt,splitk" tuning override
   int fbt = 0, fsk = 0;
-  if (force && sscanf(force, "%d,%d", &fbt, &fsk) == 2) {
-    if (fsk >= 1 && fsk <= T) sk = fsk;
+  if (force && sscanf(force, "%d,%d", &fbt, &fsk) != 2) fbt = fsk = 0;
+  static const char* t256s = getenv("SDM_WGRAD_BF16_T256");    // calibration override of the 256x256 step time [us]
+  const double t256 = t256s ? atof(t256s) * 1e-6 : 2.3e-6;
+  int sk = 1, bt = big ? 128 : 64;
+  {
+    const double out_bytes = (double)d->M * d->N * d->ntaps * d->batch * 4.0;
+    double best = 1e30;
+    for (int cand = 0; cand < 2; ++cand) {
+      int cbt = cand == 0 ? (big ? 128 : 64) : 256;
+      if (cand == 1 && !(big && d->M >= 192 && d->N >= 192)) break;
+      if (fbt == 64 || fbt == 128 || fbt == 256) {
+        if (cand == 1) break;
+        cbt = fbt;
+      }
+      const double slots = cbt == 256 ? 256.0 : (cbt == 128 ? 512.0 : 768.0);
+      const double t_step = cbt == 256 ? t256 : (cbt == 128 ? 1.45e-6 : 0.70e-6);   // one K-step of a full wave of workgroups
+      const long blocks = (long)cdiv(d->M, cbt) * cdiv(d->N, cbt) * d->ntaps * d->batch;
+      for (int c = 1; c <= 128 && c <= (T >= 4 ? T / 4 : 1); ++c) {
+        const double waves = ceil((double)blocks * c / slots);
+        const double steps = ceil((double)T / c);
+        const double t = waves * (steps * t_step + 2.0e-6) + (c > 1 || d->accumulate == 1 ? out_bytes * c / 1.3e12 : out_bytes / 5e12);
+        if (t < best * 0.97) { best = t; sk = c; bt = cbt; }     // prefer fewer slices / the earlier tile unless it pays >= 3 %
+      }
+    }
   }
+  if (fsk >= 1 && fsk <= T) sk = fsk;
+  const int ntm = cdiv(d->M, bt);
+  L.ntn = cdiv(d->N, bt);
   L.splitk = sk;
   L.atomic_out = (sk > 1 || d->accumulate == 1) ? 1 : 0;
   if (sk > 1 && d->accumulate == 0) {
@@ -388,15 +399,9 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
   if (d->Wk % BKP == 0) L.rows_per_step = 1;
   else if (BKP % d->Wk == 0 && d->Hk % (BKP / d->Wk) == 0) L.rows_per_step = BKP / d->Wk;
   else { L.rows_per_step = 0; fastp = false; }
-  const bool use128 = fbt == 128 ? true : (fbt == 64 ? false : big);
-  int ntm2 = ntm;
-  if (use128 != big) {   // forced tile: recompute the tile counts
-    const int b2 = use128 ? 128 : 64;
-    L.ntn = cdiv(d->N, b2);
-    ntm2 = cdiv(d->M, b2);
-  }
-  if (use128) return fastp ? launch_wgrad_bf16<128, 2, true>(L, ntm2, st) : launch_wgrad_bf16<128, 2, false>(L, ntm2, st);
-  return fastp ? launch_wgrad_bf16<64, 3, true>(L, ntm2, st) : launch_wgrad_bf16<64, 3, false>(L, ntm2, st);
+  if (bt == 256) return fastp ? launch_wgrad_bf16<256, 2, 4, 2, true>(L, ntm, st) : launch_wgrad_bf16<256, 2, 4, 2, false>(L, ntm, st);
+  if (bt == 128) return fastp ? launch_wgrad_bf16<128, 2, 2, 2, true>(L, ntm, st) : launch_wgrad_bf16<128, 2, 2, 2, false>(L, ntm, st);
+  return fastp ? launch_wgrad_bf16<64, 2, 2, 3, true>(L, ntm, st) : launch_wgrad_bf16<64, 2, 2, 3, false>(L, ntm, st);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -61,6 +61,7 @@ CONV_CASES = [
     ("c3s1", 3, 40, 24, 5, 7),          # K, N not multiples of the tile (but of 8)
     ("c3s1", 1, 256, 256, 4, 4),        # small M: split-K path
     ("c3s1", 8, 64, 128, 32, 32),       # 128x128-tile path (M = 8192)
+    ("c3s1", 16, 64, 256, 64, 64),      # 256x256-tile path (M = 65536, N = 256: one full round of 256 tiles)
     ("c3s2", 2, 32, 64, 8, 12),
     ("c3s2", 1, 64, 64, 7, 9),
     ("ct4", 2, 64, 32, 3, 5),
@@ -278,7 +279,7 @@ def test_residual_block_fused_tail_bf16(dev, n, c, h, w):
     assert ops.WS.buf is None or float(ops.WS.buf.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("n,c,h,w,expect", [(10, 128, 64, 64, True), (24, 256, 32, 32, True), (2, 128, 16, 16, None),
+@pytest.mark.parametrize("n,c,h,w,expect", [(10, 128, 64, 64, True), (24, 256, 32, 32, True), (16, 256, 64, 64, True), (2, 128, 16, 16, None),
                                             (3, 64, 8, 16, None), (1, 128, 12, 12, False)])
 def test_groupnorm_statistics_from_the_conv_epilogue(dev, n, c, h, w, expect):
     """sdm_igemm_bf16 with gn_sums: per-(image, channel) sum / sum of squares of the stored outputs from the conv's epilogue
@@ -304,3 +305,22 @@ def test_groupnorm_statistics_from_the_conv_epilogue(dev, n, c, h, w, expect):
     for a, b in ((s1, s0), (h1, h0), (m1, m0), (r1, r0)):
         assert rel(a, b) < 2e-5, rel(a, b)
     assert ops.GNSUMS.buf is None or float(ops.GNSUMS.buf.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("force", ["2,1", "3,1"])
+def test_large_tile_configurations_forced(force):
+    """The 256x256 / 8-wave tiles of sdm_igemm_bf16 and sdm_wgrad_bf16 (planned only for launches that fill the chip with
+    them) forced onto every shape that can take them (SDM_BF16_FORCE; read once per process -> subprocess): ragged M / N far below the tile, concat
+    sources, residual epilogues, fp32 scores, GroupNorm statistics, data gradients and the golden-pinned U-Net forward."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, SDM_BF16_FORCE=force, SDM_WGRAD_BF16_FORCE="256,2")     # weight gradients: 256x256 tile, 2 slices
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_bf16.py"),
+                        os.path.join(here, "test_gpu_bf16_train.py"), "-q", "-x", "-k",
+                        "test_conv_bf16 or concat_and_residual or attention_core or statistics_from or fwd_dgrad_wgrad or "
+                        "wgrad_bf16_concat or token_linear or forward_bf16_vs_golden or grads_bf16_vs_reference_golden"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]

@@ -35,7 +35,7 @@ def timeit(fn, warm=2, reps=5):
 
 
 def attn():
-    for n, S_, C in ((8, 4096, 512), (8, 1024, 512), (4, 1024, 512), (4, 256, 512)):
+    for n, S_, C in ((8, 4096, 512), (8, 4096, 1024), (8, 1024, 512), (4, 1024, 512), (4, 256, 512)):
         qkv = torch.randn(n * S_, 3 * C, device=DEV)
         dres = torch.randn(n * S_, C, device=DEV)
         res, P = ops.attention_core_fwd(qkv, n, S_, 1, C)
@@ -46,7 +46,14 @@ def attn():
         print(f"attention core n={n} tokens={S_} d={C}: fwd {tf*1e3:7.3f} ms {ff/tf/1e12:6.1f} TFLOP/s "
               f"({ff/tf/1e12/PEAK_FP32_MFMA_TFLOPS:4.0%} of fp32 MFMA peak) | bwd {tb*1e3:7.3f} ms {fb/tb/1e12:6.1f} TFLOP/s "
               f"({fb/tb/1e12/PEAK_FP32_MFMA_TFLOPS:4.0%})", flush=True)
-        del qkv, dres, res, P
+        # the same core on the bf16 path (scores fp32, probabilities bf16, fp32 accumulation), against the 2.5 PFLOP/s roof
+        q16, d16 = qkv.to(torch.bfloat16), dres.to(torch.bfloat16)
+        _, P16 = ops.attention_core_fwd_bf16(q16, n, S_, 1, C, keep_p=True)
+        tf16 = timeit(lambda: ops.attention_core_fwd_bf16(q16, n, S_, 1, C))
+        tb16 = timeit(lambda: ops.attention_core_bwd_bf16(d16, q16, P16, n, S_, 1, C))
+        print(f"   bf16: fwd {tf16*1e3:7.3f} ms {ff/tf16/1e12:6.1f} TFLOP/s ({ff/tf16/1e12/2500:5.1%} of bf16 MFMA peak) | "
+              f"bwd {tb16*1e3:7.3f} ms {fb/tb16/1e12:6.1f} TFLOP/s ({fb/tb16/1e12/2500:5.1%})", flush=True)
+        del qkv, dres, res, P, q16, d16, P16
         torch.cuda.empty_cache()
 
 
