@@ -242,20 +242,28 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
     __builtin_amdgcn_s_barrier();   // tile `it` visible to all waves; ring slot of tile it-1 is free again
     const float* Ab = As + buf * A_TILE + (wm * TM * 32 + l31) * ROWF;
     const float* Bb = Bs + buf * B_TILE + (wn * TN * 32 + l31) * ROWF;
+    // fragment reads run one k-group ahead of the matrix instructions (two register sets, order pinned): left to itself
+    // the compiler reads a group, drains the LDS queue and only then issues its MFMAs
+    f32x4 af[2][TM], bf[2][TN];
+    auto ldfrag = [&](int kg, int st) {
+      const int ph = ((kg * 2 + h) ^ sw_l) * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[st][i] = *(const f32x4*)(Ab + i * 32 * ROWF + ph);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[st][j] = *(const f32x4*)(Bb + j * 32 * ROWF + ph);
+    };
+    ldfrag(0, 0);
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
-      const int ph = ((kg * 2 + h) ^ sw_l) * 4;
-      f32x4 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(Ab + i * 32 * ROWF + ph);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4*)(Bb + j * 32 * ROWF + ph);
+      if (kg < 3) ldfrag(kg + 1, (kg + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
-                                                              __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[kg & 1][i]),
+                                                              __builtin_bit_cast(bf16x8, bf[kg & 1][j]), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
       // the DMA of K-step it+PD is issued in the shadow of the first MFMA group (the matrix pipe runs them
       // asynchronously), not between the barrier and the first fragment reads
       if (kg == 0) issue_next();

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdm_hip.so")
+LIB_PATH = os.environ.get("SDM_HIP_LIB") or os.path.join(_HERE, "libsdm_hip.so")     # override: kernel experiments only
 
 MAX_PHASE, MAX_TAPS = 4, 16
 ACT_NONE, ACT_SILU, ACT_TANH = 0, 1, 2
