@@ -293,3 +293,18 @@ def test_trainer_bf16_follows_fp32(dev, O):
     assert moved > 1000 and off / moved < 0.05, (off, moved)
     # the bf16 weight copies follow the optimizer: a sampling forward in bf16 after training uses fresh copies
     assert nets[1].training_dtype == BF
+
+
+@pytest.mark.parametrize("rows,C,ld", [(1000, 24, 24), (4096, 128, 128), (777, 64, 96), (50, 1536, 1536), (300, 40, 40),
+                                       (65, 20, 20), (20000, 256, 256), (9, 2056, 2056)])
+def test_colsum_bf16(dev, rows, C, ld):
+    """Column sums of bf16 rows (bias gradient of the transposed convs): the 16-byte-per-lane kernel on channel counts that
+    are / are not powers of two, padded row pitches, more than 2048 channels and C % 8 != 0 (element-wise fallback);
+    accumulates into the buffer it is handed."""
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, ld, generator=g).to(dev).to(torch.bfloat16)[:, :C]
+    out = torch.full((C,), 0.5, device=dev)
+    ops.colsum(x, out)
+    ref = x.float().sum(0) + 0.5
+    assert torch.allclose(out, ref, rtol=1e-4, atol=1e-3 * max(1.0, rows ** 0.5)), float((out - ref).abs().max())
