@@ -420,6 +420,19 @@ __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restric
     tile[i][tx] = (r < R && c < Cc) ? s[(long long)r * Cc + c] : 0.f;
   }
   __syncthreads();
+  if ((ldd & 7) == 0 && ((((unsigned long long)dst) & 15) == 0)) {
+    // 8 consecutive r per lane: one 16-byte store instead of eight 2-byte ones (rows of the copy start 16-byte aligned)
+    for (int e = threadIdx.x; e < 64 * 8; e += 256) {
+      const int i = e >> 3, r8 = (e & 7) * 8;
+      const int c = c0 + i, r = r0 + r8;
+      if (c >= Cc || r >= ldd) continue;
+      u16x8 v;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = f2bf(tile[r8 + k][i]);                // r in [R, ldd): zero padding (tile holds zeros)
+      *(u16x8*)(o + (long long)c * ldd + r) = v;
+    }
+    return;
+  }
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
     if (c < Cc && r < ldd) o[(long long)c * ldd + r] = f2bf(tile[tx][i]);      // r in [R, ldd): zero padding
