@@ -151,7 +151,8 @@ typedef struct sdm_igemm_desc {
   int defer_epilogue;     /* 1: if the library splits K, it leaves the RAW sums in ws ([out row][N], alpha / bias / act not yet
                              applied) and returns SDM_DEFERRED instead of running its finishing pass: the caller's next
                              kernel finishes them (sdm_gn_apply_fused folds the finishing pass into the GroupNorm that
-                             follows every U-Net conv block).  Only for batch == 1, no residual / out_preact / dact_z.  When
+                             follows every U-Net conv block).  Only for batch == 1, no residual / dact_z (out_preact is
+                             allowed and, like out, left unwritten when the call defers: sdm_gn_apply_fused_train).  When
                              the library does not split K the call behaves as usual and returns SDM_OK. */
 } sdm_igemm_desc;
 
@@ -231,6 +232,15 @@ int sdm_gn_apply_fused(const float* src, int64_t ld_src, int src_raw, float alph
                        int images, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
                        const float* mod, int mod_nstride, const float* x0, int64_t ldx0, const float* x1, int64_t ldx1,
                        int csplit, float* out, int64_t ldo, sdm_stream_t s);
+/* The same pass inside a TRAINING step (small layers, where the step is a chain of dependent launches): additionally
+ * leaves what the block's backward reads -- mean / rstd [images][groups] (both or neither) and, for raw sums, the conv's own
+ * finished rows y_out (activated, pitch ldy) and z_out (pre-activation, optional; same pitch).  sdm_igemm(defer_epilogue)
+ * may carry an out_preact pointer for that purpose: when it defers, it writes neither out nor out_preact. */
+int sdm_gn_apply_fused_train(const float* src, int64_t ld_src, int src_raw, float alpha, const float* bias, int act,
+                             int images, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
+                             const float* mod, int mod_nstride, const float* x0, int64_t ldx0, const float* x1,
+                             int64_t ldx1, int csplit, float* out, int64_t ldo, float* z_out, float* y_out, int64_t ldy,
+                             float* mean, float* rstd, sdm_stream_t s);
 
 /* out[r][c] = scale[n][c]*y[r][c] + shift[n][c] + cat(x0,x1)[r][c]   (ResidualBlock tail, custom_layers.py:284-286);
  * x0 NULL = affine only (materialises a conv input whose GroupNorm+AdaGN affine is pending). */

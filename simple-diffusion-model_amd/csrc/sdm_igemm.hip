@@ -896,7 +896,7 @@ static int igemm_validate(const sdm_igemm_desc* d) {
                 "igemm: affine-on-load needs K %% 4 == 0 and aligned tables");
   SDM_CHECK_ARG(d->ostride >= 1 && d->sstride >= 1 && d->Ho > 0 && d->Wo > 0, "igemm: bad strides/output dims");
   SDM_CHECK_ARG(d->act >= 0 && d->act <= 2, "igemm: bad act");
-  SDM_CHECK_ARG(!d->defer_epilogue || (d->batch == 1 && !d->res && !d->res2 && !d->out_preact && !d->dact_z),
+  SDM_CHECK_ARG(!d->defer_epilogue || (d->batch == 1 && !d->res && !d->res2 && !d->dact_z),
                 "igemm: a deferred epilogue carries only alpha / bias / activation (batch 1)");
   return SDM_OK;
 }

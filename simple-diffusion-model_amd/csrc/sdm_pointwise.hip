@@ -1253,7 +1253,9 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_kernel(float* __restrict_
                                                               const float* __restrict__ beta, const float* __restrict__ mod,
                                                               int mod_ns, const float* __restrict__ x0, long long ldx0,
                                                               const float* __restrict__ x1, long long ldx1, int csplit,
-                                                              float* __restrict__ out, long long ldo) {
+                                                              float* __restrict__ out, long long ldo,
+                                                              float* __restrict__ z_out, float* __restrict__ y_out, long long ldy,
+                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out) {
   __shared__ double red[2][16];
   __shared__ float s_stat[2];
   const int n = blockIdx.x / groups, g = blockIdx.x % groups;
@@ -1294,6 +1296,10 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_kernel(float* __restrict_
     if (var < 0.0) var = 0.0;
     s_stat[0] = (float)mean;
     s_stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (mean_out) {          // training: the backward needs the statistics
+      mean_out[blockIdx.x] = s_stat[0];
+      rstd_out[blockIdx.x] = s_stat[1];
+    }
   }
   __syncthreads();
   const float mu = s_stat[0], rstd = s_stat[1];
@@ -1304,6 +1310,16 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_kernel(float* __restrict_
     float* sp = base + pix * lds_ + c;
     const f32x4 b = (raw && bias) ? *(const f32x4*)(bias + ch) : zero4;
     f32x4 v = gnf_value(sp, raw, alpha, b, act);
+    if (raw && y_out) {      // training: the conv's own outputs (pre-activation and activated rows) for its backward
+      const long long yo = ((long long)n * HW + pix) * ldy + ch;
+      if (z_out) {
+        f32x4 zv = *(const f32x4*)sp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) zv[i] = zv[i] * alpha + b[i];
+        *(f32x4*)(z_out + yo) = zv;
+      }
+      *(f32x4*)(y_out + yo) = v;
+    }
     if (raw) *(f32x4*)sp = zero4;                       // the split-K scratch goes back zero-filled
     const f32x4 ga = *(const f32x4*)(gamma + ch), be = *(const f32x4*)(beta + ch);
     f32x4 o;
@@ -1325,10 +1341,29 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_kernel(float* __restrict_
   }
 }
 
+extern "C" int sdm_gn_apply_fused_train(const float* src, int64_t ld_src, int src_raw, float alpha, const float* bias, int act,
+                                        int images, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
+                                        const float* mod, int mod_nstride, const float* x0, int64_t ldx0, const float* x1,
+                                        int64_t ldx1, int csplit, float* out, int64_t ldo, float* z_out, float* y_out,
+                                        int64_t ldy, float* mean, float* rstd, sdm_stream_t s);
+
 extern "C" int sdm_gn_apply_fused(const float* src, int64_t ld_src, int src_raw, float alpha, const float* bias, int act,
                                   int images, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
                                   const float* mod, int mod_nstride, const float* x0, int64_t ldx0, const float* x1,
                                   int64_t ldx1, int csplit, float* out, int64_t ldo, sdm_stream_t s) {
+  return sdm_gn_apply_fused_train(src, ld_src, src_raw, alpha, bias, act, images, HW, C, groups, eps, gamma, beta, mod,
+                                  mod_nstride, x0, ldx0, x1, ldx1, csplit, out, ldo, nullptr, nullptr, 0, nullptr, nullptr, s);
+}
+
+extern "C" int sdm_gn_apply_fused_train(const float* src, int64_t ld_src, int src_raw, float alpha, const float* bias, int act,
+                                        int images, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
+                                        const float* mod, int mod_nstride, const float* x0, int64_t ldx0, const float* x1,
+                                        int64_t ldx1, int csplit, float* out, int64_t ldo, float* z_out, float* y_out,
+                                        int64_t ldy, float* mean, float* rstd, sdm_stream_t s) {
+  SDM_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "gn_apply_fused: mean and rstd come together");
+  SDM_CHECK_ARG(y_out == nullptr || (src_raw && aligned16(y_out) && ldy % 4 == 0 && (z_out == nullptr || aligned16(z_out))),
+                "gn_apply_fused: y_out / z_out are the finished rows of RAW split-K sums (16-byte aligned, pitch %% 4 == 0)");
+  SDM_CHECK_ARG(z_out == nullptr || y_out != nullptr, "gn_apply_fused: z_out needs y_out");
   SDM_CHECK_ARG(src && gamma && beta && out && images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_apply_fused: bad args");
   SDM_CHECK_ARG(x0 == nullptr || x1 != nullptr || csplit >= C, "gn_apply_fused: csplit < C without second source");
   const int cpg = C / groups;
@@ -1341,7 +1376,7 @@ extern "C" int sdm_gn_apply_fused(const float* src, int64_t ld_src, int src_raw,
   SDM_CHECK_ARG(act >= 0 && act <= 2, "gn_apply_fused: bad act");
   hipLaunchKernelGGL(gn_apply_fused_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, (float*)src, (long long)ld_src,
                      src_raw, alpha, bias, act, HW, C, groups, eps, gamma, beta, mod, mod_nstride, x0, (long long)ldx0, x1,
-                     (long long)ldx1, csplit, out, (long long)ldo);
+                     (long long)ldx1, csplit, out, (long long)ldo, z_out, y_out, (long long)ldy, mean, rstd);
   SDM_CHECK_LAUNCH("gn_apply_fused");
   return SDM_OK;
 }

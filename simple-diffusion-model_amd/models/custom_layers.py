@@ -54,6 +54,7 @@ class RunCtx:
 
 MATERIALIZE_TRAIN = [os.environ.get("SDM_TRAIN_MATERIALIZE", "1") != "0"]
 FUSE_GN = [os.environ.get("SDM_FUSE_GN", "1") != "0"]       # fused conv-block tail in no-grad forwards
+FUSE_GN_TRAIN = [os.environ.get("SDM_FUSE_GN_TRAIN", "1") != "0"]   # ... and in fp32 training steps on small layers
 FUSE_GN_BF16 = [os.environ.get("SDM_FUSE_GN_BF16", "0") == "1"]   # bf16 rows: measured neutral (N=1 0.97 -> 0.99 ms): opt-in
 FUSE_GN_MAX_BYTES = 8 << 20                                   # ... for conv outputs up to 8 MB (see ResidualBlock._fuse_this)
 
@@ -446,6 +447,18 @@ class UNet_ConvBlock(nn.Module):
         gn = self.adagn.group_norm
         return ops.gn_apply_fused(y, gn.weight, gn.bias, mod, gn.groups, residual=residual)
 
+    def run_fused_train(self, ctx, x, emb, residual=None):
+        """run_fused inside a training step (fp32 rows, small layers): same single-launch tail, which also leaves the
+        conv's rows, its pre-activation and the GroupNorm statistics for the backward."""
+        c = self.conv_layer.conv
+        act = ACT_SILU if self.use_activation else ACT_NONE
+        mod = ctx.mods[self.adagn] if ctx.mods is not None else self.adagn.modulation(emb)
+        y = ops.conv_fwd(x, c.taps_for(ctx), c.bias, "c3s1", act, save_z=self.use_activation, defer=True)
+        gn = self.adagn.group_norm
+        out, ya, mean, rstd = ops.gn_apply_fused(y, gn.weight, gn.bias, mod, gn.groups, residual=residual, train=True)
+        ctx.rec[self] = (x, ya, mod, mean, rstd)
+        return out
+
     def backward(self, ctx, g, grads, res=None, res2=None):
         """g: gradient w.r.t. this block's output -- the modulated tensor when AdaGN is present, else the conv's
         pre-activation gradient (dz)."""
@@ -492,10 +505,27 @@ class ResidualBlock(nn.Module):
             return False
         return c % (4 * a1.group_norm.groups) == 0 and c % (4 * a2.group_norm.groups) == 0
 
+    def _fuse_train(self, ctx, x, emb):
+        """fp32 training step on small layers (the batch-4 headline: every launch of its dependent chain costs ~4.5 us):
+        the materialising path below is conv [+ split-K finishing pass] + statistics + apply per conv block, the fused
+        tail one launch after the conv."""
+        if not ctx.train or ctx.bf16 or emb is None or not FUSE_GN_TRAIN[0] or not MATERIALIZE_TRAIN[0] or x.scale is not None:
+            return False
+        a1, a2 = getattr(self.conv_block_1, "adagn", None), getattr(self.conv_block_2, "adagn", None)
+        if a1 is None or a2 is None:
+            return False
+        c = self.conv_block_1.conv_layer.conv.cout
+        if x.rows * c * 4 > FUSE_GN_MAX_BYTES:
+            return False
+        return c % (4 * a1.group_norm.groups) == 0 and c % (4 * a2.group_norm.groups) == 0
+
     def run(self, ctx, x, emb=None):
         if self._fuse_this(ctx, x, emb):
             x2 = self.conv_block_1.run_fused(ctx, x, emb)
             return self.conv_block_2.run_fused(ctx, x2, emb, residual=x)
+        if self._fuse_train(ctx, x, emb):
+            x2 = self.conv_block_1.run_fused_train(ctx, x, emb)
+            return self.conv_block_2.run_fused_train(ctx, x2, emb, residual=x)
         y1, aff1 = self.conv_block_1.run(ctx, x, emb)
         if (ctx.bf16 or (ctx.train and MATERIALIZE_TRAIN[0])) and aff1 is not None:
             # the affine is materialised: the LDS-DMA tiles cannot apply it on the fly.  bf16 rows always; in training

@@ -246,10 +246,11 @@ class Deferred:
     """A conv output whose split-K finishing pass has NOT run: raw sums [rows, c] in the shared zero-filled scratch
     (WS.buf), plus what the finishing pass would have applied.  Consumed -- and the scratch cleared -- by the very next
     launch (gn_apply_fused); nothing else may touch WS in between."""
-    __slots__ = ("ws", "n", "h", "w", "c", "bias", "act", "dtype")
+    __slots__ = ("ws", "n", "h", "w", "c", "bias", "act", "dtype", "out", "z")
 
-    def __init__(self, ws, n, h, w, c, bias, act, dtype=torch.float32):
+    def __init__(self, ws, n, h, w, c, bias, act, dtype=torch.float32, out=None, z=None):
         self.ws, self.n, self.h, self.w, self.c, self.bias, self.act, self.dtype = ws, n, h, w, c, bias, act, dtype
+        self.out, self.z = out, z        # training: the (still unwritten) rows the finishing kernel must produce
 
 
 def to_bf16(t, out=None):
@@ -334,14 +335,14 @@ def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False, defer=False, gn_stat
     d.Ho, d.Wo = ho, wo
     d.out, d.ldo = _p(out), out.stride(0)
     d.bias, d.act, d.out_preact = _p(bias), act, _p(z)
-    d.defer_epilogue = int(bool(defer) and not save_z)
+    d.defer_epilogue = int(bool(defer) and (not save_z or not bf))      # fp32: the fused training tail writes z as well
     sums = None
     if gn_stats and bf and CONV_GN_STATS[0] and kind == "c3s1":
         sums = GNSUMS.get(x.n * cout * 2 * 4, wt.device)       # zero-filled; consumed (and cleared) by sdm_gn_finalize
         d.gn_sums = _p(sums)
     rc = _launch_igemm(d, wt.device, bf16=bf)
     if rc == lib.DEFERRED:
-        return Deferred(WS.buf, x.n, ho, wo, cout, bias, act, BF16 if bf else torch.float32)
+        return Deferred(WS.buf, x.n, ho, wo, cout, bias, act, BF16 if bf else torch.float32, out=out if save_z else None, z=z)
     y = Act(out, x.n, ho, wo, z=z)
     if rc == lib.STATS_DONE:
         y.stats = sums
@@ -788,9 +789,11 @@ def gn_affine(y, gamma, beta, mod, groups=32, eps=1e-5, want_stats=True):
     return scale, shift, mean, rstd
 
 
-def gn_apply_fused(y, gamma, beta, mod, groups=32, eps=1e-5, residual=None):
-    """out = s * GroupNorm(y) + s (+ cat(residual.t, residual.t2)) in ONE launch (no-grad forwards); y: a plain fp32 Act or
-    a Deferred conv output, whose finishing pass (bias, activation) is folded in.  Returns a plain Act."""
+def gn_apply_fused(y, gamma, beta, mod, groups=32, eps=1e-5, residual=None, train=False):
+    """out = s * GroupNorm(y) + s (+ cat(residual.t, residual.t2)) in ONE launch; y: a plain fp32 Act or a Deferred conv
+    output, whose finishing pass (bias, activation) is folded in.  Returns a plain Act; with ``train`` (fp32 rows)
+    (out, y, mean, rstd): the conv's own rows (activated, with ``z`` where the conv kept a pre-activation) and the GroupNorm
+    statistics, i.e. what UNet_ConvBlock records for its backward."""
     C_ = y.c
     dev = gamma.device
     dt = y.dtype if isinstance(y, Deferred) else y.t.dtype
@@ -802,6 +805,21 @@ def gn_apply_fused(y, gamma, beta, mod, groups=32, eps=1e-5, residual=None):
         src, ld, raw, bias, act = y.ws, C_, 1, y.bias, y.act
     else:
         src, ld, raw, bias, act = y.t, y.t.stride(0), 0, None, ACT_NONE
+    if train:
+        if dt == BF16:
+            raise lib.SdmError("gn_apply_fused(train=True): fp32 rows only")
+        mean = torch.empty((y.n, groups), dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        if raw:
+            yrows = y.out if y.out is not None else torch.empty((y.n * y.h * y.w, C_), dtype=dt, device=dev)
+            ya = Act(yrows, y.n, y.h, y.w, z=y.z)
+        else:
+            yrows, ya = None, y
+        lib.call("sdm_gn_apply_fused_train", _p(src), ld, raw, 1.0, _p(bias), act, y.n, y.h * y.w, C_, groups, eps, _p(gamma),
+                 _p(beta), _p(mod), mns, _p(x0), x0.stride(0) if x0 is not None else 0, _p(x1),
+                 x1.stride(0) if x1 is not None else 0, residual.c1 if x1 is not None else (1 << 30), _p(out), out.stride(0),
+                 _p(ya.z) if raw else None, _p(yrows), yrows.stride(0) if raw else 0, _p(mean), _p(rstd), _stream())
+        return Act(out, y.n, y.h, y.w), ya, mean, rstd
     lib.call("sdm_gn_apply_fused_bf16" if dt == BF16 else "sdm_gn_apply_fused", _p(src), ld, raw, 1.0, _p(bias), act, y.n, y.h * y.w, C_, groups, eps, _p(gamma), _p(beta),
              _p(mod), mns, _p(x0), x0.stride(0) if x0 is not None else 0, _p(x1), x1.stride(0) if x1 is not None else 0,
              residual.c1 if x1 is not None else (1 << 30), _p(out), out.stride(0), _stream())
