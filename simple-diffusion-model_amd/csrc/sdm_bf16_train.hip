@@ -309,6 +309,200 @@ static int launch_wgrad_bf16(const WgradBfLaunch& L, int ntm, hipStream_t st) {
   return SDM_OK;
 }
 
+// --------------------------------------------------------------------------------------------
+// Three taps per workgroup for plain 3x3 stride-1 weight gradients on feature maps at least 64 pixels wide.
+// wgrad_bf16_kernel gives every tap its own workgroups, each streaming the same gradient tile and an activation tile
+// shifted by one pixel; what bounds these kernels is the volume moved L2 -> LDS (profiles/r02_bf16_tiles.txt).  Here a
+// workgroup owns one kernel ROW (dy) of a 128x128 (c_out x c_in) tile: per 64-pixel K-step it loads the gradient rows once
+// and the 66 activation pixels x0-1 .. x0+64 of image row y+dy once, and contracts the three column taps dx = -1, 0, +1
+// from the same LDS image (fragment rows shifted by 1 + dx, swizzle taken from the shifted row): a third of the bytes per
+// flop, 48 instead of 16 MFMAs per wave and barrier, 1.33 instead of 2 transposing reads per MFMA.
+// --------------------------------------------------------------------------------------------
+struct Wgrad3Launch {
+  sdm_wgrad_desc d;
+  int splitk, ntn, atomic_out;
+  int dy[3];           // kernel-row offsets handled by blockIdx.y = 0..2
+  int tapw[3][3];      // weight tap index of (dy index, dx = -1, 0, +1)
+};
+
+#define W3_XROWS 68     // 66 activation pixels per K-step, padded to whole 4-row DMA instructions
+
+__global__ __launch_bounds__(256, 2) void wgrad3_bf16_kernel(const Wgrad3Launch L) {
+  const sdm_wgrad_desc& d = L.d;
+  constexpr int BT = 128, TM = 2, TN = 2, ROWB = 2 * BT, NBUF = 2;
+  constexpr int GT = BKP * ROWB, XT = W3_XROWS * ROWB;          // bytes per stage: 16 KiB + 17 KiB
+  extern __shared__ __align__(16) char smem_w3[];
+  char* Gs = smem_w3;
+  char* Xs = smem_w3 + NBUF * GT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
+  const int ntiles_ = gridDim.x / L.splitk;
+  const int wg_ = xcd_contiguous_wg(blockIdx.x, gridDim.x);
+  const int ks = wg_ / ntiles_, tile_ = wg_ - ks * ntiles_;
+  const int tile_n = tile_ % L.ntn, tile_m = tile_ / L.ntn;
+  const int dyi = blockIdx.y, dy = L.dy[dyi];
+  const int m0 = tile_m * BT, n0 = tile_n * BT;
+  const bf16_t* g0 = (const bf16_t*)d.g.p0;
+  const bf16_t* x0 = (const bf16_t*)d.x.p0;
+  const bf16_t* x1 = (const bf16_t*)d.x.p1;
+  const bf16_t* zero = (const bf16_t*)g_zero_chunk_wg;
+  const int H = d.Hk, W = d.Wk, HW = H * W;
+  const long long P = (long long)d.images * HW;
+  const int T = (int)(P / BKP);                                 // W % 64 == 0: K-steps are whole 64-pixel row pieces
+  const int it0 = (int)((long long)T * ks / L.splitk), it1 = (int)((long long)T * (ks + 1) / L.splitk);
+  // DMA roles: 16 chunks per 256-byte row, 16 rows per pass of the 256 threads
+  const int drow = tid >> 4;
+  const int cm = m0 + 8 * ((tid & 15) ^ ((drow & 3) << 2));      // gradient rows: swizzle by the pixel row (drow + 16 i: same & 3)
+  const bool gch = cm < ((d.M + 7) & ~7);
+  const bool do_bias = d.dbias != nullptr && tile_n == 0 && dyi == 0;
+  float bacc = 0.f;
+  // activation patch row r <-> pixel x0 - 1 + r; rows r = drow + 16 i (i = 0..3) and, wave 0 only, 64 + (tid >> 4)
+  // (r & 3) == (drow & 3) for all of them, so one logical chunk column serves every pass
+  const int cn = n0 + 8 * ((tid & 15) ^ ((drow & 3) << 2));
+  const bool xch = cn < ((d.N + 7) & ~7);
+  const bool xsrc0 = cn < d.x.csplit;
+  const bf16_t* xb = xsrc0 ? x0 : x1;
+  const long long xld = xsrc0 ? d.x.ld0 : d.x.ld1;
+  const int xcol = xsrc0 ? cn : cn - d.x.csplit;
+
+  int un, uy, ux;
+  {
+    const long long p0 = (long long)it0 * BKP;
+    un = (int)(p0 / HW);
+    const int rem = (int)(p0 - (long long)un * HW);
+    uy = rem / W;
+    ux = rem - uy * W;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  int issued = it0;
+  auto issue_next = [&]() {
+    if (issued < it1) {
+      const int buf = (issued - it0) & 1;
+      char* Gd = Gs + buf * GT + wave * 1024;
+      char* Xd = Xs + buf * XT + wave * 1024;
+      const long long grow0 = ((long long)un * H + uy) * W + ux;                 // gradient pixel of row 0 of the step
+      const int xy = uy + dy;
+      const bool yok = (unsigned)xy < (unsigned)H;
+      const long long xrow0 = ((long long)un * H + xy) * W + ux - 1;              // activation pixel of patch row 0
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = drow + 16 * i;
+        const bf16_t* gq = gch ? g0 + (grow0 + r) * d.g.ld0 + cm : zero;
+        const int px = ux - 1 + r;
+        const bool xu = xch && yok && (unsigned)px < (unsigned)W;
+        const bf16_t* xq = xu ? xb + (xrow0 + r) * xld + xcol : zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr)gq, (lds_ptr)(Gd + i * 16 * ROWB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)xq, (lds_ptr)(Xd + i * 16 * ROWB), 16, 0, 0);
+      }
+      if (wave == 0) {                          // patch rows 64..67 (pixels x0+63 .. x0+66; 66, 67 are never read: zeros)
+        const int r = 64 + drow;                // drow = 0..3 in wave 0
+        const int px = ux - 1 + r;
+        const bool xu = xch && yok && r < 66 && (unsigned)px < (unsigned)W;
+        const bf16_t* xq = xu ? xb + (xrow0 + r) * xld + xcol : zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr)xq, (lds_ptr)(Xs + buf * XT + 64 * ROWB), 16, 0, 0);
+      }
+      ux += BKP;
+      if (ux >= W) { ux = 0; uy += 1; }
+      if (uy >= H) { uy = 0; un += 1; }
+    }
+    ++issued;
+  };
+
+  // transposing-read roles (see wgrad_bf16_kernel): 16-lane group row q, channel quad p4
+  const int i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, chalf = (lane >> 4) & 1;
+  int aoff[TM], boff[3][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int col = wm * TM * 32 + i * 32 + 16 * chalf + 4 * p4;
+    aoff[i] = (8 * h + q) * ROWB + (((col >> 3) ^ (q << 2)) << 4) + ((col & 4) << 1);
+  }
+#pragma unroll
+  for (int sft = 0; sft < 3; ++sft)              // patch rows shifted by 1 + dx = 0, 1, 2
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = wn * TN * 32 + j * 32 + 16 * chalf + 4 * p4;
+      boff[sft][j] = (8 * h + q + sft) * ROWB + (((col >> 3) ^ (((q + sft) & 3) << 2)) << 4) + ((col & 4) << 1);
+    }
+
+  f32x16 acc[3][TM][TN];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+  typedef __attribute__((address_space(3))) s16x4* tr_ptr;
+  issue_next();
+  for (int it = it0; it < it1; ++it) {
+    const int buf = (it - it0) & 1;
+    wait_vmcnt_wg<0>();
+    __builtin_amdgcn_s_barrier();
+    issue_next();
+    const char* Ab = Gs + buf * GT;
+    const char* Bb = Xs + buf * XT;
+    if (do_bias && tid < BT) {
+      float a = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < BKP; ++k) a += bf2f(*(const bf16_t*)(Ab + k * ROWB + (((tid >> 3) ^ ((k & 3) << 2)) << 4) + ((tid & 7) << 1)));
+      bacc += a;
+    }
+#pragma unroll
+    for (int kk = 0; kk < BKP / 16; ++kk) {
+      s16x8 af[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Ab + aoff[i] + (kk * 16) * ROWB));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Ab + aoff[i] + (kk * 16 + 4) * ROWB));
+        af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int sft = 0; sft < 3; ++sft) {
+        s16x8 bf[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Bb + boff[sft][j] + (kk * 16) * ROWB));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Bb + boff[sft][j] + (kk * 16 + 4) * ROWB));
+          bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[sft][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                     __builtin_bit_cast(bf16x8, bf[j]), acc[sft][i][j], 0, 0, 0);
+      }
+    }
+  }
+  if (do_bias && tid < BT && m0 + tid < d.M) atomicAdd(&d.dbias[m0 + tid], bacc);
+
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int sft = 0; sft < 3; ++sft) {
+    float* dw = d.dw + (long long)L.tapw[dyi][sft] * d.w_tap_stride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + l31;
+        if (col >= d.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row >= d.M) continue;
+          float* o = dw + (long long)row * d.ldw + col;
+          const float v = acc[sft][i][j][r] * d.alpha;
+          if (L.atomic_out) atomicAdd(o, v);
+          else *o = v;
+        }
+      }
+  }
+}
+
 __global__ void zero_rows_f32_kernel(float* p, long long rows, int cols, long long ld) {
   const long long total = rows * cols;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -379,7 +573,47 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
       }
     }
   }
-  if (fsk >= 1 && fsk <= T) sk = fsk;
+  // three taps per workgroup (wgrad3_bf16_kernel): plain 3x3 stride-1 geometry on maps at least 64 pixels wide
+  bool use3 = false;
+  Wgrad3Launch L3;
+  {
+    static const char* w3 = getenv("SDM_WGRAD3");                // "0": off; "1": on wherever eligible (tests); default: cost model
+    static const char* t3s = getenv("SDM_WGRAD3_T");             // calibration override of its step time [us]
+    bool ok = !(w3 && w3[0] == '0') && d->ntaps == 9 && d->batch == 1 && d->g_stride == 1 && d->x_stride == 1 && d->Wk % BKP == 0 &&
+              d->g.H == d->Hk && d->g.W == d->Wk && d->x.H == d->Hk && d->x.W == d->Wk && d->M >= 96 && d->N >= 96 &&
+              (fbt == 0 || fbt == 3);
+    int seen[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int t = 0; ok && t < 9; ++t) {
+      const int ty = d->x_dy[t], tx = d->x_dx[t];
+      if (d->g_dy[t] != 0 || d->g_dx[t] != 0 || ty < -1 || ty > 1 || tx < -1 || tx > 1 || seen[ty + 1][tx + 1]) ok = false;
+      else { seen[ty + 1][tx + 1] = 1; L3.tapw[ty + 1][tx + 1] = d->tap_w[t]; }
+    }
+    if (ok) {
+      const double t3 = t3s ? atof(t3s) * 1e-6 : 2.5e-6;          // one K-step of a full wave of 512 workgroups (3 taps each)
+      const long blocks3 = (long)cdiv(d->M, 128) * cdiv(d->N, 128) * 3;
+      const double out_bytes = (double)d->M * d->N * 9 * 4.0;
+      double best3 = 1e30, best_other = 1e30;
+      int sk3 = 1;
+      for (int c = 1; c <= 128 && c <= (T >= 4 ? T / 4 : 1); ++c) {
+        const double t = ceil((double)blocks3 * c / 512.0) * (ceil((double)T / c) * t3 + 2.0e-6) +
+                         (c > 1 || d->accumulate == 1 ? out_bytes * c / 1.3e12 : out_bytes / 5e12);
+        if (t < best3 * 0.97) { best3 = t; sk3 = c; }
+      }
+      {   // the cost of the choice made above (same formula)
+        const double slots = bt == 256 ? 256.0 : (bt == 128 ? 512.0 : 768.0);
+        const double t_step = bt == 256 ? t256 : (bt == 128 ? 1.45e-6 : 0.70e-6);
+        const long blocks = (long)cdiv(d->M, bt) * cdiv(d->N, bt) * d->ntaps;
+        best_other = ceil((double)blocks * sk / slots) * (ceil((double)T / sk) * t_step + 2.0e-6) +
+                     (sk > 1 || d->accumulate == 1 ? out_bytes * sk / 1.3e12 : out_bytes / 5e12);
+      }
+      if ((w3 && w3[0] == '1') || fbt == 3 || best3 < best_other) {
+        use3 = true;
+        sk = (fbt == 3 && fsk >= 1 && fsk <= T) ? fsk : sk3;
+        for (int i = 0; i < 3; ++i) L3.dy[i] = i - 1;
+      }
+    }
+  }
+  if (!use3 && fsk >= 1 && fsk <= T) sk = fsk;
   const int ntm = cdiv(d->M, bt);
   L.ntn = cdiv(d->N, bt);
   L.splitk = sk;
@@ -392,6 +626,28 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
                            (long long)d->ldw);
         SDM_CHECK_LAUNCH("zero_rows");
       }
+  }
+  if (use3) {
+    L3.d = *d;
+    L3.splitk = sk;
+    L3.atomic_out = L.atomic_out;
+    L3.ntn = cdiv(d->N, 128);
+    constexpr size_t lds3 = (size_t)2 * (BKP * 256 + W3_XROWS * 256);
+    static bool attr3 = false;
+    if (!attr3) {
+      (void)hipFuncSetAttribute((const void*)wgrad3_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      attr3 = true;
+    }
+    {
+      const double px = (double)d->images;
+      const double g_b = px * d->g.H * d->g.W * d->M, x_b = px * d->x.H * d->x.W * d->N, w_b = (double)d->M * d->N * 9;
+      sdm_prof_shape(d->M, d->N, (int)P, 9, sk, 2.0 * (g_b + x_b) + 4.0 * w_b);
+    }
+    sdm_prof_pre(st);
+    hipLaunchKernelGGL(wgrad3_bf16_kernel, dim3(cdiv(d->M, 128) * L3.ntn * sk, 3, 1), dim3(256), lds3, st, L3);
+    sdm_prof_post(st, 3, 2.0 * d->M * d->N * (double)P * 9);
+    SDM_CHECK_LAUNCH("wgrad3_bf16");
+    return SDM_OK;
   }
   // structured pixel walk when a 64-pixel K-step is an aligned piece of one image row or a whole number of rows
   static const char* nofast = getenv("SDM_WGRAD_BF16_FASTP");

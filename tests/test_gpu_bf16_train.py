@@ -77,6 +77,9 @@ CONV_CASES = [
     ("c3s1", 3, 40, 24, 5, 7),          # ragged channels (multiples of 8 only), odd image
     ("c3s1", 1, 256, 256, 4, 4),        # 16 pixels: a single, mostly empty K-step
     ("c3s1", 4, 64, 192, 32, 32),
+    ("c3s1", 1, 128, 128, 8, 64),       # 64-pixel-wide maps: eligible for the three-tap weight-gradient kernel
+    ("c3s1", 2, 136, 200, 4, 64),       # ... ragged channel counts
+    ("c3s1", 1, 96, 256, 3, 128),       # ... two K-steps per image row, odd row count
     ("c3s2", 2, 32, 64, 8, 12),
     ("c3s2", 1, 64, 64, 7, 9),
     ("ct4", 2, 64, 32, 3, 5),
@@ -122,11 +125,12 @@ def test_conv_fwd_dgrad_wgrad_bf16(dev, L, kind, n, cin, cout, h, w):
     assert rel(grads[conv.bias], bref.grad) < 1e-4, rel(grads[conv.bias], bref.grad)
 
 
-def test_wgrad_bf16_concat_input_and_accumulate(dev, L):
+@pytest.mark.parametrize("h,w", [(12, 12), (6, 64)])
+def test_wgrad_bf16_concat_input_and_accumulate(dev, L, h, w):
     """Two-pointer (channel-concat) activation rows, and accumulation into a non-zero gradient buffer."""
     from sdm_hip import ops
     g = torch.Generator().manual_seed(11)
-    n, c1, c2, cout, h, w = 2, 64, 128, 128, 12, 12
+    n, c1, c2, cout = 2, 64, 128, 128
     x1, x2 = r16(torch.randn(n, c1, h, w, generator=g)), r16(torch.randn(n, c2, h, w, generator=g))
     dz = r16(torch.randn(n, cout, h, w, generator=g))
     wref = torch.zeros(cout, c1 + c2, 3, 3, requires_grad=True)
@@ -308,3 +312,19 @@ def test_colsum_bf16(dev, rows, C, ld):
     ops.colsum(x, out)
     ref = x.float().sum(0) + 0.5
     assert torch.allclose(out, ref, rtol=1e-4, atol=1e-3 * max(1.0, rows ** 0.5)), float((out - ref).abs().max())
+
+
+def test_three_tap_weight_gradient_kernel_forced():
+    """wgrad3_bf16_kernel (one kernel row = three column taps per workgroup; planned for 3x3 stride-1 convs on maps >= 64
+    pixels wide once the launch is large) forced onto every eligible case of this file (SDM_WGRAD3=1; read once per process
+    -> subprocess): the 64- / 128-wide conv cases above incl. ragged channels, concat rows, accumulation, the fused bias
+    gradient, and the whole-network gradient goldens."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, SDM_WGRAD3="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "fwd_dgrad_wgrad or concat_input or grads_bf16_vs_reference_golden"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
