@@ -327,6 +327,11 @@ struct Wgrad3Launch {
 
 #define W3_XROWS 68     // 66 activation pixels per K-step, padded to whole 4-row DMA instructions
 
+// WSH: 6 = maps at least 64 pixels wide (a K-step is a piece of one image row); 5 / 4 = 32 / 16 pixels wide: a K-step is
+// 2 / 4 whole rows, the activation "row" is the same 66 consecutive pixels of the (dy-shifted) linear pixel index, and the
+// products whose gradient pixel has no left / right neighbour are dropped by zeroing fixed fragment elements (pixel k of a
+// step sits in element k & 7 of k-group k >> 4, half (k >> 3) & 1: x == 0 <=> k % W == 0 is a compile-time position).
+template <int WSH>
 __global__ __launch_bounds__(256, 2) void wgrad3_bf16_kernel(const Wgrad3Launch L) {
   const sdm_wgrad_desc& d = L.d;
   constexpr int BT = 128, TM = 2, TN = 2, ROWB = 2 * BT, NBUF = 2;
@@ -386,12 +391,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3_bf16_kernel(const Wgrad3Launch 
       const int xy = uy + dy;
       const bool yok = (unsigned)xy < (unsigned)H;
       const long long xrow0 = ((long long)un * H + xy) * W + ux - 1;              // activation pixel of patch row 0
+      const int lin0 = xy * W + ux - 1;                                          // ... as a pixel index inside its image
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = drow + 16 * i;
         const bf16_t* gq = gch ? g0 + (grow0 + r) * d.g.ld0 + cm : zero;
         const int px = ux - 1 + r;
-        const bool xu = xch && yok && (unsigned)px < (unsigned)W;
+        const bool xu = WSH >= 6 ? (xch && yok && (unsigned)px < (unsigned)W) : (xch && (unsigned)(lin0 + r) < (unsigned)HW);
         const bf16_t* xq = xu ? xb + (xrow0 + r) * xld + xcol : zero;
         __builtin_amdgcn_global_load_lds((glb_ptr)gq, (lds_ptr)(Gd + i * 16 * ROWB), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_ptr)xq, (lds_ptr)(Xd + i * 16 * ROWB), 16, 0, 0);
@@ -399,12 +405,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3_bf16_kernel(const Wgrad3Launch 
       if (wave == 0) {                          // patch rows 64..67 (pixels x0+63 .. x0+66; 66, 67 are never read: zeros)
         const int r = 64 + drow;                // drow = 0..3 in wave 0
         const int px = ux - 1 + r;
-        const bool xu = xch && yok && r < 66 && (unsigned)px < (unsigned)W;
+        const bool xu = r < 66 && (WSH >= 6 ? (xch && yok && (unsigned)px < (unsigned)W) : (xch && (unsigned)(lin0 + r) < (unsigned)HW));
         const bf16_t* xq = xu ? xb + (xrow0 + r) * xld + xcol : zero;
         __builtin_amdgcn_global_load_lds((glb_ptr)xq, (lds_ptr)(Xs + buf * XT + 64 * ROWB), 16, 0, 0);
       }
-      ux += BKP;
-      if (ux >= W) { ux = 0; uy += 1; }
+      if (WSH >= 6) {
+        ux += BKP;
+        if (ux >= W) { ux = 0; uy += 1; }
+      } else {
+        uy += BKP >> WSH;
+      }
       if (uy >= H) { uy = 0; un += 1; }
     }
     ++issued;
@@ -468,6 +478,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3_bf16_kernel(const Wgrad3Launch 
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Bb + boff[sft][j] + (kk * 16) * ROWB));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Bb + boff[sft][j] + (kk * 16 + 4) * ROWB));
           bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        if (WSH < 6 && sft != 1) {          // narrow maps: gradient pixels at x == 0 (dx = -1) / x == W - 1 (dx = +1) have no neighbour
+          const bool grp = WSH == 4 || (sft == 0 ? (kk & 1) == 0 : (kk & 1) == 1);
+          if (grp && h == (sft == 0 ? 0 : 1)) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j][sft == 0 ? 0 : 7] = 0;
+          }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -579,7 +596,8 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
   {
     static const char* w3 = getenv("SDM_WGRAD3");                // "0": off; "1": on wherever eligible (tests); default: cost model
     static const char* t3s = getenv("SDM_WGRAD3_T");             // calibration override of its step time [us]
-    bool ok = !(w3 && w3[0] == '0') && d->ntaps == 9 && d->batch == 1 && d->g_stride == 1 && d->x_stride == 1 && d->Wk % BKP == 0 &&
+    bool ok = !(w3 && w3[0] == '0') && d->ntaps == 9 && d->batch == 1 && d->g_stride == 1 && d->x_stride == 1 &&
+              (d->Wk % BKP == 0 || ((d->Wk == 32 || d->Wk == 16) && ((long)d->Hk * d->Wk) % BKP == 0)) &&
               d->g.H == d->Hk && d->g.W == d->Wk && d->x.H == d->Hk && d->x.W == d->Wk && d->M >= 96 && d->N >= 96 &&
               (fbt == 0 || fbt == 3);
     int seen[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -635,7 +653,9 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
     constexpr size_t lds3 = (size_t)2 * (BKP * 256 + W3_XROWS * 256);
     static bool attr3 = false;
     if (!attr3) {
-      (void)hipFuncSetAttribute((const void*)wgrad3_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      (void)hipFuncSetAttribute((const void*)wgrad3_bf16_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      (void)hipFuncSetAttribute((const void*)wgrad3_bf16_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      (void)hipFuncSetAttribute((const void*)wgrad3_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
       attr3 = true;
     }
     {
@@ -644,7 +664,10 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
       sdm_prof_shape(d->M, d->N, (int)P, 9, sk, 2.0 * (g_b + x_b) + 4.0 * w_b);
     }
     sdm_prof_pre(st);
-    hipLaunchKernelGGL(wgrad3_bf16_kernel, dim3(cdiv(d->M, 128) * L3.ntn * sk, 3, 1), dim3(256), lds3, st, L3);
+    const dim3 grid3(cdiv(d->M, 128) * L3.ntn * sk, 3, 1);
+    if (d->Wk >= 64) hipLaunchKernelGGL(wgrad3_bf16_kernel<6>, grid3, dim3(256), lds3, st, L3);
+    else if (d->Wk == 32) hipLaunchKernelGGL(wgrad3_bf16_kernel<5>, grid3, dim3(256), lds3, st, L3);
+    else hipLaunchKernelGGL(wgrad3_bf16_kernel<4>, grid3, dim3(256), lds3, st, L3);
     sdm_prof_post(st, 3, 2.0 * d->M * d->N * (double)P * 9);
     SDM_CHECK_LAUNCH("wgrad3_bf16");
     return SDM_OK;

@@ -80,6 +80,9 @@ CONV_CASES = [
     ("c3s1", 1, 128, 128, 8, 64),       # 64-pixel-wide maps: eligible for the three-tap weight-gradient kernel
     ("c3s1", 2, 136, 200, 4, 64),       # ... ragged channel counts
     ("c3s1", 1, 96, 256, 3, 128),       # ... two K-steps per image row, odd row count
+    ("c3s1", 2, 128, 160, 8, 32),       # ... 32 / 16 pixels wide: a K-step is 2 / 4 rows, edge products masked
+    ("c3s1", 3, 96, 128, 16, 16),
+    ("c3s1", 1, 128, 128, 4, 16),       # ... one K-step per image
     ("c3s2", 2, 32, 64, 8, 12),
     ("c3s2", 1, 64, 64, 7, 9),
     ("ct4", 2, 64, 32, 3, 5),
