@@ -413,6 +413,275 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
   }
 }
 
+// --------------------------------------------------------------------------------------------
+// 3x3 stride-1 convs (forward and data gradient): one activation patch per kernel ROW.
+//
+// What bounds igemm_bf16_kernel is the volume moved L2 -> LDS (profiles/r02_bf16_tiles.txt), and the three taps of one
+// kernel row (dx = -1, 0, +1) read the same BM consecutive pixels shifted by one.  Here a tile is BM consecutive pixels of
+// one image; for a kernel row dy and a 64-channel chunk the BM + 2 pixels  t0 + dy W - 1 .. t0 + dy W + BM  are loaded
+// ONCE (pixels outside the image from a zero chunk) and the three taps read their fragments from that image at row offset
+// 1 + dx; lanes whose output pixel sits at x = 0 / W - 1 zero their fragment for dx = -1 / +1 (the patch holds the wrapped
+// neighbour there).  Per K-step (one tap, 64 channels) only the weight tile moves: a third of the activation bytes, the
+// K-step itself (32 MFMAs per wave and barrier at 256x256) unchanged.  LDS image as in igemm_bf16_kernel (128-byte rows,
+// chunk ^ (row >> 1) & 7: conflict-free for any start row).  A full 9-tap halo (profiles: tools/scratch/halo) needed
+// 32-channel steps to fit LDS and lost on the matrix side; one row at a time fits with 64-channel steps.
+// --------------------------------------------------------------------------------------------
+struct RowLaunch {
+  sdm_igemm_desc d;
+  int ntn, W, wmask, gn_stats;
+  int dy[3];            // kernel-row offsets in the order they are walked
+  int tapw[3][3];       // weight tap index of (row index, dx = -1, 0, +1)
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_row_bf16_kernel(const RowLaunch L) {
+  const sdm_igemm_desc& d = L.d;
+  constexpr int NT = 64 * WM * WN, NWAVE = WM * WN;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int PROWS = BM + 2;                           // patch pixels
+  constexpr int PINST = (PROWS + 7) / 8;                  // 1-KiB DMA instructions per patch (8 rows of 128 B each)
+  constexpr int PW = (PINST + NWAVE - 1) / NWAVE;         // ... per wave
+  constexpr int PBYTES = 128 + PINST * 1024;              // one guard row in front (read by masked lanes only)
+  constexpr int BIT = BN / (8 * NWAVE);                   // weight-tile DMA instructions per wave (BN rows of 128 B)
+  constexpr int BSTAGE = BN * 128;
+  extern __shared__ __align__(16) char smem_r[];
+  char* Pb = smem_r;                                      // 2 patch buffers
+  char* Bs = smem_r + 2 * PBYTES;                         // 2 weight stages
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
+  const int tile_id = xcd_contiguous_bf(blockIdx.x, gridDim.x);
+  const int tile_n = tile_id % L.ntn, tile_m = tile_id / L.ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int W = L.W, H = d.a.H, HW = H * W;
+  const int img = m0 / HW, t0 = m0 - img * HW;             // tile start as a pixel index inside its image
+  const int K = d.K, N = d.N, csplit = d.a.csplit;
+  const int KC = K / BKE, kc0 = (csplit < K ? csplit : K) / BKE;
+  const bf16_t* a0 = (const bf16_t*)d.a.p0;
+  const bf16_t* a1 = (const bf16_t*)d.a.p1;
+  const bf16_t* bw = (const bf16_t*)d.b;
+  const bf16_t* zero = (const bf16_t*)g_zero_chunk_bf;
+  if (tid < 64) ((unsigned*)(Pb + (tid >> 5) * PBYTES))[tid & 31] = 0u;     // the zero row in front of either patch
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  // ---- DMA roles: patch instruction k * NWAVE + wave covers patch rows 8 * inst .. +7; lane -> row lane >> 3, physical
+  // chunk lane & 7, logical chunk = physical ^ swizzle(row)
+  const int prl = lane >> 3;
+  int pchunk[PW];
+#pragma unroll
+  for (int k = 0; k < PW; ++k) {
+    const int row = (k * NWAVE + wave) * 8 + prl;
+    pchunk[k] = 8 * ((lane & 7) ^ ((row >> 1) & 7));
+  }
+  const bf16_t* bp[BIT];
+  bool bok[BIT];
+#pragma unroll
+  for (int k = 0; k < BIT; ++k) {
+    const int n = (k * NWAVE + wave) * 8 + prl;
+    bok[k] = n0 + n < N;
+    bp[k] = bw + (long long)(n0 + n) * d.ldb + 8 * ((lane & 7) ^ ((n >> 1) & 7));
+  }
+  auto issue_patch = [&](int ri, int kc, int buf) {        // kernel row ri, chunk kc -> patch buffer buf
+    const int lin0 = t0 + L.dy[ri] * W - 1;                // image pixel index of patch row 0
+    const bool second = kc >= kc0;
+    const bf16_t* src = second ? a1 : a0;
+    const long long ld = second ? d.a.ld1 : d.a.ld0;
+    const int ch = (second ? kc - kc0 : kc) * BKE;
+    char* dst = Pb + buf * PBYTES + 128 + wave * 1024;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const int inst = k * NWAVE + wave;
+      if (inst < PINST) {
+        const int lin = lin0 + inst * 8 + prl;
+        const bool ok = (unsigned)lin < (unsigned)HW && inst * 8 + prl < PROWS;
+        const bf16_t* p = ok ? src + ((long long)img * HW + lin) * ld + ch + pchunk[k] : zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(dst + k * NWAVE * 1024), 16, 0, 0);
+      }
+    }
+  };
+  auto issue_b = [&](int ri, int dxi, int kc, int slot) {
+    const long long off = (long long)L.tapw[ri][dxi] * d.b_tap_stride + kc * BKE;
+    char* dst = Bs + slot * BSTAGE + wave * 1024;
+#pragma unroll
+    for (int k = 0; k < BIT; ++k) {
+      const bf16_t* p = bok[k] ? bp[k] + off : zero;
+      __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(dst + k * NWAVE * 1024), 16, 0, 0);
+    }
+  };
+  // ---- fragment roles
+  // patch row of (tile pixel t, dx) is t + 1 + dx; lanes whose pixel has no left / right neighbour read the zeroed guard
+  // row in front of the patch instead (one select per step, nothing per k-group)
+  int t128[TM];
+  unsigned deadm = 0;                                       // bit 2i: no left neighbour, bit 2i + 1: no right neighbour
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int t = wm * TM * 32 + i * 32 + l31;              // tile pixel
+    const int tx = (t0 + t) & L.wmask;
+    t128[i] = t * 128;
+    if (tx == 0) deadm |= 1u << (2 * i);
+    if (tx == W - 1) deadm |= 2u << (2 * i);
+  }
+  int boff[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) boff[j] = (wn * TN * 32 + j * 32 + l31) * 128;
+  const int sw_b = (l31 >> 1) & 7;                          // weight rows: (n >> 1) & 7 == (l31 >> 1) & 7 (32-row blocks)
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  __syncthreads();
+  const int NP = 3 * KC;                                    // patches: (kernel row, chunk), chunk fastest
+  issue_patch(0, 0, 0);
+  issue_b(0, 0, 0, 0);
+  int ri = 0, kc = 0;                                       // (kernel row, chunk) of the patch being computed
+  for (int pi = 0; pi < NP; ++pi) {
+    int nri = ri, nkc = kc + 1;                             // ... of the next patch
+    if (nkc == KC) { nkc = 0; ++nri; }
+    const char* Pq = Pb + (pi & 1) * PBYTES + 128;
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi) {
+      const int s = pi * 3 + dxi;
+      wait_vmcnt_bf<0>();
+      __builtin_amdgcn_s_barrier();                         // stage s (and patch pi) visible; stage s - 1 / patch pi - 1 free
+      if (dxi < 2) issue_b(ri, dxi + 1, kc, (s + 1) & 1);
+      else if (pi + 1 < NP) issue_b(nri, 0, nkc, (s + 1) & 1);
+      if (dxi == 0 && pi + 1 < NP) issue_patch(nri, nkc, (pi + 1) & 1);
+      const char* Bq = Bs + (s & 1) * BSTAGE;
+      f32x4 af[2][TM], bf[2][TN];
+      int aoff[TM];                                         // (the chunk swizzle (q >> 1) & 7 is bits 8..10 of q * 128)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const bool dead = dxi == 0 ? (deadm >> (2 * i)) & 1u : (dxi == 2 ? (deadm >> (2 * i + 1)) & 1u : false);
+        aoff[i] = dead ? -128 : t128[i] + dxi * 128;
+      }
+      auto ldfrag = [&](int kg, int st) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[st][i] = *(const f32x4*)(Pq + aoff[i] + (((kg * 2 + h) ^ ((aoff[i] >> 8) & 7)) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[st][j] = *(const f32x4*)(Bq + boff[j] + (((kg * 2 + h) ^ sw_b) << 4));
+      };
+      ldfrag(0, 0);
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) {
+        if (kg < 3) ldfrag(kg + 1, (kg + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[kg & 1][i]),
+                                                                __builtin_bit_cast(bf16x8, bf[kg & 1][j]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    ri = nri;
+    kc = nkc;
+  }
+
+  // ---- epilogue (the vector epilogue of igemm_bf16_kernel; output row of tile row r is m0 + r)
+  bf16_t* out16 = (bf16_t*)d.out;
+  bf16_t* pre16 = (bf16_t*)d.out_preact;
+  const bf16_t* res16 = (const bf16_t*)d.res;
+  const bf16_t* res216 = (const bf16_t*)d.res2;
+  const bf16_t* dz16 = (const bf16_t*)d.dact_z;
+  constexpr size_t LDSB = (size_t)2 * PBYTES + 2 * BSTAGE;
+  constexpr int SL = ((size_t)BM * BN * 4 <= LDSB) ? 1 : 2;
+  constexpr int TMS = TM / SL;
+  static_assert(TM % SL == 0 && (size_t)(BM / SL) * BN * 4 <= LDSB, "output slab must fit");
+  float* Ct = (float*)smem_r;
+  constexpr int C4 = BN / 4;
+  static_assert(NT % C4 == 0, "a thread keeps one column quad");
+  f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int sl = 0; sl < SL; ++sl) {
+    __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < TMS; ++ii)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int prow_ = wm * TMS * 32 + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          Ct[prow_ * BN + wn * TN * 32 + j * 32 + l31] = acc[sl * TMS + ii][j][r];
+        }
+    __syncthreads();
+#pragma unroll 2
+    for (int e = tid; e < (BM / SL) * C4; e += NT) {
+      const int prow_ = e / C4, c4 = (e - prow_ * C4) * 4;
+      const int row = SL == 1 ? prow_ : (prow_ / (TMS * 32)) * (TM * 32) + sl * (TMS * 32) + prow_ % (TMS * 32);
+      const int col = n0 + c4;
+      const long long orow = m0 + row;
+      if (col >= N) continue;
+      f32x4 v = *(const f32x4*)(Ct + prow_ * BN + c4);
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (d.bias) bv = *(const f32x4*)(d.bias + col);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = v[q] * d.alpha + bv[q];
+      if (pre16) {
+        u16x4 zo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zo[q] = f2bf(v[q]);
+        *(u16x4*)(pre16 + orow * d.ldo + col) = zo;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = sdm_act(v[q], d.act);
+      if (res16) {
+        const u16x4 rv = *(const u16x4*)(res16 + orow * d.ldres + col);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += bf2f(rv[q]);
+      }
+      if (res216) {
+        const u16x4 rv = *(const u16x4*)(res216 + orow * d.ldres2 + col);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += bf2f(rv[q]);
+      }
+      if (dz16 && (d.dact_ncols == 0 || col < d.dact_ncols)) {
+        const u16x4 zv = *(const u16x4*)(dz16 + orow * d.ldz + col);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] *= sdm_dsilu(bf2f(zv[q]));
+      }
+      u16x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = f2bf(v[q]);
+      *(u16x4*)(out16 + orow * d.ldo + col) = o;
+      if (L.gn_stats) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float r = bf2f(o[q]);
+          gs[q] += r;
+          gq[q] = fmaf(r, r, gq[q]);
+        }
+      }
+    }
+  }
+  if (L.gn_stats) {
+    constexpr int GT = NT / C4;
+    __syncthreads();
+    float* red = (float*)smem_r;
+    *(f32x4*)(red + (tid * 2) * 4) = gs;
+    *(f32x4*)(red + (tid * 2 + 1) * 4) = gq;
+    __syncthreads();
+    if (tid < BN && n0 + tid < N) {
+      const int cg = tid >> 2, q = tid & 3;
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int g = 0; g < GT; ++g) {
+        a += red[((g * C4 + cg) * 2) * 4 + q];
+        b += red[((g * C4 + cg) * 2 + 1) * 4 + q];
+      }
+      float* dst = d.gn_sums + ((long long)img * N + n0 + tid) * 2;
+      atomicAdd(dst, a);
+      atomicAdd(dst + 1, b);
+    }
+  }
+}
+
 // finishes a split-K contraction (ws [batch entry][out row][N] raw fp32 sums, left zero-filled); rows = per entry
 __global__ __launch_bounds__(256) void splitk_epilogue_bf16_kernel(const sdm_igemm_desc d, long long rows, int out_f32) {
   const long long total = rows * d.batch * d.N;
@@ -537,6 +806,55 @@ static int launch_bf(const BfLaunch& L, int ntm, hipStream_t st) {
   return SDM_OK;
 }
 
+// row-patch kernel: plain 3x3 stride-1 geometry (forward or data gradient), image width a power of two, tiles inside one
+// image, unsplit, vector epilogue.  Returns 0 (not eligible) or the tile edge (128: the kernel replaces the 128x128 tiles of
+// igemm_bf16_kernel; a 256x256 variant ran out of registers and lost to the plain 256x256 tile, profiles/r02_bf16_tiles.txt).
+static int row_tile(const sdm_igemm_desc* d, int out_f32, int vec_epi, RowLaunch* R) {
+  static const char* sw = getenv("SDM_BF16_ROW");          // "0": off
+  if (sw && sw[0] == '0') return 0;
+  if (out_f32 || !vec_epi || d->batch != 1 || d->nphase != 1 || d->sstride != 1 || d->ostride != 1 || d->defer_epilogue) return 0;
+  if (d->ntaps[0] != 9 || d->Ht != d->a.H || d->Wt != d->a.W || d->Ho != d->Ht || d->Wo != d->Wt) return 0;
+  const int W = d->a.W, H = d->a.H;
+  if (W < 2 || (W & (W - 1)) != 0 || ((long)H * W) % 128 != 0) return 0;
+  if (d->K % BKE != 0 || (d->a.p1 != nullptr && d->a.csplit % BKE != 0) || d->N < 64) return 0;
+  int seen[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int t = 0; t < 9; ++t) {
+    const int ty = d->tap_dy[0][t], tx = d->tap_dx[0][t];
+    if (ty < -1 || ty > 1 || tx < -1 || tx > 1 || seen[ty + 1][tx + 1]) return 0;
+    seen[ty + 1][tx + 1] = 1;
+    R->tapw[ty + 1][tx + 1] = d->tap_w[0][t];
+  }
+  for (int i = 0; i < 3; ++i) R->dy[i] = i - 1;
+  R->W = W;
+  R->wmask = W - 1;
+  return 128;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_row(const sdm_igemm_desc* d, RowLaunch& R, int gn_stats, hipStream_t st) {
+  constexpr int PINST = (BM + 2 + 7) / 8;
+  constexpr size_t lds = (size_t)2 * (128 + PINST * 1024) + (size_t)2 * BN * 128;
+  static bool attr_set = false;
+  auto kern = conv3_row_bf16_kernel<BM, BN, WM, WN>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  R.d = *d;
+  R.ntn = cdiv(d->N, BN);
+  R.gn_stats = gn_stats;
+  {
+    const double images = (double)d->M / ((double)d->Ht * d->Wt);
+    const double in_b = images * d->a.H * d->a.W * d->K, w_b = (double)d->K * d->N * 9, out_b = images * d->Ho * d->Wo * d->N;
+    sdm_prof_shape(d->M, d->N, d->K, 9, 1, 2.0 * (in_b + w_b + out_b));
+  }
+  sdm_prof_pre(st);
+  hipLaunchKernelGGL(kern, dim3((d->M / BM) * R.ntn), dim3(64 * WM * WN), lds, st, R);
+  sdm_prof_post(st, 0, 2.0 * d->M * d->N * d->K * 9);
+  SDM_CHECK_LAUNCH("conv3_row_bf16");
+  return SDM_OK;
+}
+
 extern "C" size_t sdm_igemm_bf16_workspace_bytes(const sdm_igemm_desc* d) {
   if (bf_validate(d, 0) != SDM_OK) return 0;
   int b, sk;
@@ -588,6 +906,16 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
   L.gn_stats = d->gn_sums != nullptr && !out_f32 && L.vec_epi && L.splitk == 1 && d->batch == 1 && d->nphase == 1 &&
                d->ostride == 1 && d->sstride == 1 && d->Ht == d->Ho && d->Wt == d->Wo && d->N % 4 == 0 &&
                ((long)d->Ho * d->Wo) % kBfCfgs[cfg].bm == 0;
+  static const char* rowsw = getenv("SDM_BF16_ROW");        // "0": never, "1": wherever eligible (tests)
+  if ((cfg == 0 && L.splitk == 1) || (rowsw && rowsw[0] == '1')) {
+    RowLaunch R;
+    if (row_tile(d, out_f32, L.vec_epi, &R)) {      // 3x3 stride-1 geometry: one activation patch per kernel row
+      const int gs = d->gn_sums != nullptr && d->N % 4 == 0;      // a tile lies inside one image by construction
+      rc = launch_row<128, 128, 2, 2>(d, R, gs, st);
+      if (rc != SDM_OK) return rc;
+      return gs ? SDM_STATS_DONE : SDM_OK;
+    }
+  }
   if (cfg == 0) rc = fast ? launch_bf<128, 128, 2, 2, 2, true>(L, ntm, st) : launch_bf<128, 128, 2, 2, 2, false>(L, ntm, st);
   else if (cfg == 1) rc = fast ? launch_bf<64, 64, 2, 2, 3, true>(L, ntm, st) : launch_bf<64, 64, 2, 2, 3, false>(L, ntm, st);
   else if (cfg == 2 && fast && L.vec_epi && L.splitk == 1) rc = launch_bf<256, 256, 2, 4, 2, true>(L, ntm, st);

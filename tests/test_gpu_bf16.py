@@ -62,6 +62,10 @@ CONV_CASES = [
     ("c3s1", 1, 256, 256, 4, 4),        # small M: split-K path
     ("c3s1", 8, 64, 128, 32, 32),       # 128x128-tile path (M = 8192)
     ("c3s1", 16, 64, 256, 64, 64),      # 256x256-tile path (M = 65536, N = 256: one full round of 256 tiles)
+    ("c3s1", 12, 64, 128, 64, 64),      # row-patch kernel as planned (384 tiles of 128x128, 3x3 stride-1)
+    ("c3s1", 1, 128, 72, 8, 16),        # ... its edge cases when forced (test below): one tile = a whole 8x16 image,
+    ("c3s1", 2, 64, 128, 2, 64),        # a tile = two image rows, ragged N
+    ("c3s1", 1, 192, 128, 1, 128),      # a one-row image
     ("c3s2", 2, 32, 64, 8, 12),
     ("c3s2", 1, 64, 64, 7, 9),
     ("ct4", 2, 64, 32, 3, 5),
@@ -322,5 +326,24 @@ def test_large_tile_configurations_forced(force):
                         os.path.join(here, "test_gpu_bf16_train.py"), "-q", "-x", "-k",
                         "test_conv_bf16 or concat_and_residual or attention_core or statistics_from or fwd_dgrad_wgrad or "
                         "wgrad_bf16_concat or token_linear or forward_bf16_vs_golden or grads_bf16_vs_reference_golden"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_row_patch_kernel_forced():
+    """conv3_row_bf16_kernel (3x3 stride-1 convs: one activation patch per kernel row serves its three column taps; planned
+    where the 128x128 tiles would run) forced onto every eligible shape of the bf16 suites (SDM_BF16_ROW=1; subprocess):
+    single-tile images, tiles of several rows, one-row images, ragged channel counts, concat sources, residual / SiLU'
+    epilogues of the data gradient, GroupNorm statistics, and the golden-pinned forward / gradients of whole networks."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, SDM_BF16_ROW="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_bf16.py"),
+                        os.path.join(here, "test_gpu_bf16_train.py"), "-q", "-x", "-k",
+                        "test_conv_bf16 or concat_and_residual or statistics_from or fwd_dgrad_wgrad or "
+                        "forward_bf16_vs_golden or grads_bf16_vs_reference_golden or fused_tail"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]

@@ -29,8 +29,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 import torch
 for shape in sys.argv[1:]:
     ref = None
-    for force in ("0,1", "4,1", "5,1"):
-        env = dict(os.environ, SDM_BF16_FORCE=force)
+    for force in ("0", "d"):
+        env = dict(os.environ)
+        if force != "d": env["SDM_BF16_ROW"] = force
         f = f"/tmp/tile_{force[0]}.pt"
         r = subprocess.run([sys.executable, __file__, "child", f] + shape.split("x"), env=env, capture_output=True, text=True, timeout=200)
         line = (r.stdout.strip().splitlines() or ["?"])[-1]
