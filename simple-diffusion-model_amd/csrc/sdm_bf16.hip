@@ -11,6 +11,7 @@
 // so operand movement, not the matrix pipe, sets the pace (see the tile configurations below).
 #include <stdlib.h>
 
+#define SDM_FAST_SIGMOID
 #include "sdm_common.h"
 
 #define BKE 64   // reduction elements per K-step (128 bytes)

@@ -12,6 +12,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#define SDM_FAST_SIGMOID
 #include "sdm_common.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));

@@ -43,7 +43,13 @@ extern unsigned long long g_sdm_launches;   // kernel launches issued by the lib
       return sdm_set_error(SDM_ERR_LAUNCH, "hipMemsetAsync failed");             \
   } while (0)
 
+// SDM_FAST_SIGMOID (defined by the bf16 translation units before this header): v_rcp_f32 (1 ulp) instead of the IEEE
+// division sequence -- the result is rounded to bf16 right after; the fp32 path keeps the exact quotient.
+#ifdef SDM_FAST_SIGMOID
+__device__ __forceinline__ float sdm_sigmoid(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+#else
 __device__ __forceinline__ float sdm_sigmoid(float z) { return 1.0f / (1.0f + __expf(-z)); }
+#endif
 __device__ __forceinline__ float sdm_silu(float z) { return z * sdm_sigmoid(z); }
 __device__ __forceinline__ float sdm_dsilu(float z) {
   float s = sdm_sigmoid(z);
