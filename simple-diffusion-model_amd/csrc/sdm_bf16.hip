@@ -291,6 +291,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
     constexpr int C4 = BN / 4;
     static_assert(NT % C4 == 0, "a thread keeps one column quad across its rows");
     f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};     // GroupNorm statistics of this thread's 4 columns
+    // a thread keeps its column quad over all its rows (NT % C4 == 0): the bias is loaded once, not per row
+    const int mycol = n0 + (tid % C4) * 4;
+    const f32x4 bias4 = (d.bias && mycol < N) ? *(const f32x4*)(d.bias + mycol) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int sl = 0; sl < SL; ++sl) {
       __syncthreads();                       // every wave is done with the last K-step's fragments / the previous slab
@@ -312,10 +315,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
         const long long orow = s_orow[row];
         if (orow < 0 || col >= N) continue;
         f32x4 v = *(const f32x4*)(Ct + prow * BN + c4);
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (d.bias) bv = *(const f32x4*)(d.bias + col);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] * d.alpha + bv[q];
+        for (int q = 0; q < 4; ++q) v[q] = v[q] * d.alpha + bias4[q];
         if (pre16) {     // pre-activation copy for the backward (training)
           u16x4 zo;
 #pragma unroll
@@ -599,6 +600,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_ro
   constexpr int C4 = BN / 4;
   static_assert(NT % C4 == 0, "a thread keeps one column quad");
   f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
+  const int mycol = n0 + (tid % C4) * 4;           // a thread keeps its column quad over all its rows: bias loaded once
+  const f32x4 bias4 = (d.bias && mycol < N) ? *(const f32x4*)(d.bias + mycol) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int sl = 0; sl < SL; ++sl) {
     __syncthreads();
@@ -620,10 +623,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_ro
       const long long orow = m0 + row;
       if (col >= N) continue;
       f32x4 v = *(const f32x4*)(Ct + prow_ * BN + c4);
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (d.bias) bv = *(const f32x4*)(d.bias + col);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = v[q] * d.alpha + bv[q];
+      for (int q = 0; q < 4; ++q) v[q] = v[q] * d.alpha + bias4[q];
       if (pre16) {
         u16x4 zo;
 #pragma unroll
