@@ -599,7 +599,7 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
     static const char* t3s = getenv("SDM_WGRAD3_T");             // calibration override of its step time [us]
     bool ok = !(w3 && w3[0] == '0') && d->ntaps == 9 && d->batch == 1 && d->g_stride == 1 && d->x_stride == 1 &&
               (d->Wk % BKP == 0 || ((d->Wk == 32 || d->Wk == 16) && ((long)d->Hk * d->Wk) % BKP == 0)) &&
-              d->g.H == d->Hk && d->g.W == d->Wk && d->x.H == d->Hk && d->x.W == d->Wk && d->M >= 96 && d->N >= 96 &&
+              d->g.H == d->Hk && d->g.W == d->Wk && d->x.H == d->Hk && d->x.W == d->Wk &&
               (fbt == 0 || fbt == 3);
     int seen[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int t = 0; ok && t < 9; ++t) {
@@ -625,7 +625,10 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
         best_other = ceil((double)blocks * sk / slots) * (ceil((double)T / sk) * t_step + 2.0e-6) +
                      (sk > 1 || d->accumulate == 1 ? out_bytes * sk / 1.3e12 : out_bytes / 5e12);
       }
-      if ((w3 && w3[0] == '1') || fbt == 3 || best3 < best_other) {
+      // the 3- / 6-channel edge convs (one side of the tile almost empty) on full-resolution maps: measured 223 -> 162 us at
+      // 524288 pixels, which the per-tap model (calibrated on full tiles) does not see
+      const bool edge = (d->M < 64 || d->N < 64) && T >= 1024;
+      if ((w3 && w3[0] == '1') || fbt == 3 || best3 < best_other || edge) {
         use3 = true;
         sk = (fbt == 3 && fsk >= 1 && fsk <= T) ? fsk : sk3;
         for (int i = 0; i < 3; ++i) L3.dy[i] = i - 1;
