@@ -909,7 +909,10 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
                d->ostride == 1 && d->sstride == 1 && d->Ht == d->Ho && d->Wt == d->Wo && d->N % 4 == 0 &&
                ((long)d->Ho * d->Wo) % kBfCfgs[cfg].bm == 0;
   static const char* rowsw = getenv("SDM_BF16_ROW");        // "0": never, "1": wherever eligible (tests)
-  if ((cfg == 0 && L.splitk == 1) || (rowsw && rowsw[0] == '1')) {
+  // the planner sends launches of fewer than 320 128x128 tiles to the 64x64 tiles; the row-patch kernel is worth it from one
+  // tile per CU on (8192 x 512, 512 channels: 487 -> 640 TFLOP/s; at 128 tiles the 64x64 tiles win, 534 vs 322)
+  const bool row_mid = cfg == 1 && L.splitk == 1 && (long)cdiv(d->M, 128) * cdiv(d->N, 128) >= 256;
+  if ((cfg == 0 && L.splitk == 1) || row_mid || (rowsw && rowsw[0] == '1')) {
     RowLaunch R;
     if (row_tile(d, out_f32, L.vec_epi, &R)) {      // 3x3 stride-1 geometry: one activation patch per kernel row
       const int gs = d->gn_sums != nullptr && d->N % 4 == 0;      // a tile lies inside one image by construction
