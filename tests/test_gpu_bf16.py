@@ -344,6 +344,6 @@ def test_row_patch_kernel_forced():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_bf16.py"),
                         os.path.join(here, "test_gpu_bf16_train.py"), "-q", "-x", "-k",
                         "test_conv_bf16 or concat_and_residual or statistics_from or fwd_dgrad_wgrad or "
-                        "forward_bf16_vs_golden or grads_bf16_vs_reference_golden or fused_tail"],
+                        "forward_bf16_vs_golden or grads_bf16_vs_reference_golden or fused_tail or standard_architecture"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
