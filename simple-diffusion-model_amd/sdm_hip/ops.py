@@ -5,6 +5,7 @@ Activations are NHWC "pixel rows x channels" (class Act); conv weights are tap-m
 ``[taps, c_out, c_in]`` views of the parameters (see models/custom_layers.py).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -975,6 +976,9 @@ def area_resize(x, size):
     return out
 
 
+BANK_MFMA = [os.environ.get("SDM_BANK_MFMA", "1") != "0"]
+
+
 class LinearBank:
     """The y_scale projections of every AdaGN in the net, evaluated in ONE launch (sdm_linear_multi) and
     differentiated w.r.t. the shared embedding in ONE launch (sdm_linear_multi_bwd_dx).  Holds the device job
@@ -1032,7 +1036,13 @@ class LinearBank:
                     setattr(self, k, v)
             self.key = key
         keep(self.built[key])
-        lib.call("sdm_linear_multi", _p(emb), emb.stride(0), M, K, _p(self.jobs), len(linears), self.maxO, _stream())
+        if M >= 32 and BANK_MFMA[0] and emb.is_contiguous():
+            # large batches (C3: 128 U-Net images): one matrix-core GEMM per projection instead of the small-M VALU kernel
+            # (0.55 ms of a 27.5 ms forward); the launch count does not matter there
+            for l, v in zip(linears, self.views):
+                linear_rows(emb, l.weight, l.bias, out=v)
+        else:
+            lib.call("sdm_linear_multi", _p(emb), emb.stride(0), M, K, _p(self.jobs), len(linears), self.maxO, _stream())
         if not private:
             return self.views
         # training: the modulation rows are read again by backward, possibly after another forward has reused the

@@ -876,3 +876,19 @@ def test_residual_block_fused_tail_vs_oracle(dev, L, O, n, c, h, w):
         assert rel(y, y0) < 5e-6
     # the deferred epilogue left the shared split-K scratch zero-filled
     assert ops.WS.buf is None or float(ops.WS.buf.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("m", [4, 40, 128])
+def test_modulation_bank_small_and_large_batch(dev, L, m):
+    """ops.LinearBank: the y_scale projections of all AdaGN blocks from one embedding batch -- the small-M kernel (one launch)
+    below 32 rows, one matrix-core GEMM per projection from 32 rows on (batched sampling, C3) -- against x @ W^T + b."""
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(m)
+    lins = [L.TapLinear(64, o).to(dev) for o in (128, 96, 256)]
+    emb = torch.randn(m, 64, generator=g).to(dev)
+    bank = ops.LinearBank()
+    views = bank.forward(lins, emb)
+    for l, v in zip(lins, views):
+        ref = emb @ l.weight.detach().t() + l.bias.detach()
+        assert v.shape == ref.shape
+        assert rel(v, ref) < 2e-6, rel(v, ref)
