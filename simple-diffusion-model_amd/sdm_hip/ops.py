@@ -1036,9 +1036,9 @@ class LinearBank:
                     setattr(self, k, v)
             self.key = key
         keep(self.built[key])
-        if M >= 32 and BANK_MFMA[0] and emb.is_contiguous():
+        if M >= 64 and BANK_MFMA[0] and emb.is_contiguous():
             # large batches (C3: 128 U-Net images): one matrix-core GEMM per projection instead of the small-M VALU kernel
-            # (0.55 ms of a 27.5 ms forward); the launch count does not matter there
+            # (0.55 ms of a 27.5 ms forward); at 32 rows (C4 training) the 20 extra launches cost more than they save
             for l, v in zip(linears, self.views):
                 linear_rows(emb, l.weight, l.bias, out=v)
         else:

@@ -881,7 +881,7 @@ def test_residual_block_fused_tail_vs_oracle(dev, L, O, n, c, h, w):
 @pytest.mark.parametrize("m", [4, 40, 128])
 def test_modulation_bank_small_and_large_batch(dev, L, m):
     """ops.LinearBank: the y_scale projections of all AdaGN blocks from one embedding batch -- the small-M kernel (one launch)
-    below 32 rows, one matrix-core GEMM per projection from 32 rows on (batched sampling, C3) -- against x @ W^T + b."""
+    below 64 rows, one matrix-core GEMM per projection from 64 rows on (batched sampling, C3) -- against x @ W^T + b."""
     from sdm_hip import ops
     g = torch.Generator().manual_seed(m)
     lins = [L.TapLinear(64, o).to(dev) for o in (128, 96, 256)]
