@@ -269,27 +269,61 @@ def multi_gpu_report(dev, world, rank, sched, tr64, x64):
     tr64.reducer.world = world
     rep["step_ms_with_allreduce"], rep["step_ms_without_allreduce"] = with_ar, without
     rep["allreduce_exposed_ms"] = with_ar - without
-    # C4 shape under data parallelism
-    torch.manual_seed(0)
-    net = U_Net(**STANDARD).to(dev)
-    tr = DiffusionTrainer(net, sched, lr=2e-5, seed=77)
-    x0 = torch.randn(32, 3, 128, 128, device=dev)
-    dist.barrier()
-    ms = time_gpu(lambda: tr.step(x0), 2, 4)
-    tm = torch.tensor([ms], device=dev, dtype=torch.float64)
-    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-    rep["c4_ms_per_step"] = float(tm)
-    rep["c4_steps_per_s"] = 1e3 / float(tm)
-    rep["c4_images_per_s"] = world * 32 * 1e3 / float(tm)
-    rep["c4_config"] = "128x128, 32 images per GPU, fp32, DDPM training, global batch %d" % (32 * world)
-    del tr, net, x0
-    torch.cuda.empty_cache()
+    # C4 shape under data parallelism (BASELINE configs[3]: 128x128, 32 images per GPU), fp32 and the bf16 training path
+    for tag, kw in (("", {}), ("_bf16", {"train_dtype": torch.bfloat16})):
+        torch.manual_seed(0)
+        net = U_Net(**STANDARD).to(dev)
+        tr = DiffusionTrainer(net, sched, lr=2e-5, seed=77, **kw)
+        x0 = torch.randn(32, 3, 128, 128, device=dev)
+        dist.barrier()
+        ms = time_gpu(lambda: tr.step(x0), 2, 4)
+        tm = torch.tensor([ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        rep["c4%s_ms_per_step" % tag] = float(tm)
+        rep["c4%s_steps_per_s" % tag] = 1e3 / float(tm)
+        rep["c4%s_images_per_s" % tag] = world * 32 * 1e3 / float(tm)
+        del tr, net, x0
+        torch.cuda.empty_cache()
+    rep["c4_config"] = "128x128, 32 images per GPU, DDPM training, global batch %d; fp32 and bf16 storage" % (32 * world)
     return rep
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher around it: THIS process becomes the launcher.  It starts N fresh
+    interpreters of this file, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly
+    what `python -m torch.distributed.run --nproc-per-node N` would set), relays rank 0's JSON line (rank 0 inherits
+    stdout; the other ranks' stdout goes to stderr) and exits with the ranks' return code.  The launcher itself never
+    touches the GPU (no torch.cuda call, no library import) and never replaces itself with another program."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            try:
+                code = p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:          # one rank failed: the others would wait in a collective forever
+                    q.terminate()
+    return rc
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch")
@@ -297,10 +331,30 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SDM_BENCH_DRYRUN") == "1":
+        # launcher rehearsal without a GPU (tests/test_abi_and_host.py): the ranks rendezvous over gloo, count themselves
+        # with an all-reduce and rank 0 prints what the communicator saw
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        one = torch.ones(1)
+        dist.all_reduce(one)
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": dist.get_world_size(), "ranks_counted": int(one.item()),
+                              "gpus_arg": args.gpus}))
+        dist.destroy_process_group()
+        return
     local = local % max(1, torch.cuda.device_count())     # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -311,6 +365,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from models.U_Net import U_Net
     import degraders

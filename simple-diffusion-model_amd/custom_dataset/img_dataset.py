@@ -18,6 +18,19 @@ def _load_bgr_u8(path):
     return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)[:, :, ::-1])
 
 
+def _shuffle_records(records):
+    """The reference shuffles the records once, unseeded, at construction (conditional_img_dataset.py:33,
+    doodle_dataset.py:38): harmless there, it has one process.  Under data parallelism (WORLD_SIZE > 1) every rank builds
+    its own dataset object, and DistributedSampler / CachedLoader hand out INDEX shards -- disjoint only if all ranks hold
+    the same record order -- so there the shuffle is seeded identically on every rank (SDM_DATA_SEED, default
+    a constant); a single process keeps the reference's plain random.shuffle."""
+    import random
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        random.Random(int(os.environ.get("SDM_DATA_SEED", "20240229"))).shuffle(records)
+    else:
+        random.shuffle(records)
+
+
 def _load_bgr(path):
     """img_dataset.py:26-36: (img.astype(float) - 127.5) / 127.5 in float64, then .float(), then CHW."""
     bgr = _load_bgr_u8(path)
@@ -59,7 +72,6 @@ class ConditionalImgDataset(Dataset):
     exceptions when either is empty; the initial shuffle of the records is kept (seedable through ``random``)."""
 
     def __init__(self, dataset_path=None):
-        import random
         with open(dataset_path) as f:
             db = json.load(f)
         data_tbl, labels_tbl = db.get("Data", {}), db.get("Labels", {})
@@ -70,7 +82,7 @@ class ConditionalImgDataset(Dataset):
         by_id = lambda tbl: [tbl[k] for k in sorted(tbl, key=lambda s: int(s))]      # TinyDB.all() order: document id
         self.all_labels = by_id(labels_tbl)[0]["labels"]
         self.all_data = by_id(data_tbl)
-        random.shuffle(self.all_data)
+        _shuffle_records(self.all_data)
         self.root = os.path.dirname(os.path.abspath(dataset_path))
         self.dataset = [(d["filename"], [float(d[label]) for label in self.all_labels]) for d in self.all_data]
 
@@ -95,7 +107,6 @@ class DoodleImgDataset(Dataset):
     dataset, the FIRST entry of the "Labels" list naming the key that holds the label image's path."""
 
     def __init__(self, dataset_path=None):
-        import random
         with open(dataset_path) as f:
             db = json.load(f)
         data_tbl, labels_tbl = db.get("Data", {}), db.get("Labels", {})
@@ -106,7 +117,7 @@ class DoodleImgDataset(Dataset):
         by_id = lambda tbl: [tbl[k] for k in sorted(tbl, key=lambda s: int(s))]
         self.all_labels = by_id(labels_tbl)[0]["labels"]
         self.all_data = by_id(data_tbl)
-        random.shuffle(self.all_data)
+        _shuffle_records(self.all_data)
         self.root = os.path.dirname(os.path.abspath(dataset_path))
         label = self.all_labels[0]
         self.dataset = [(d["filename"], d[label]) for d in self.all_data]

@@ -150,7 +150,7 @@ def run_training(sr=False, mode=None):
         cache = DeviceImageCache(dataset, dev, log=logging.info)
         loader = CachedLoader(cache, cfg["batch_size"], rank, world, flip=cfg["flip_imgs"], generator=trainer.gen,
                               conditional=cfg["use_conditional"])
-        sampler, cached = loader if world > 1 else None, True
+        sampler, cached = loader, True          # set_epoch() every epoch at any world size: fresh permutation per epoch
         logging.info(f"device cache: {len(cache):,} images, {cache.images.numel() / 2**20:.1f} MiB of HBM")
     opt = trainer.opt
     if ckpt is not None and cfg["load_diffusion_optim"]:

@@ -255,4 +255,5 @@ class DiffusionTrainer:
             self.hyper[0:1].fill_(lr)
             self._lr_dev = lr
         self.graph.replay()
+        ops.WEIGHT_EPOCH[0] += 1          # the replayed Adam rewrote the weights: bf16 copies of no-grad forwards are stale
         return self.g_loss

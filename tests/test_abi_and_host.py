@@ -208,3 +208,59 @@ def test_normalisation_table_matches_the_reference_arithmetic():
     ref = torch.from_numpy((v.astype(float) - 127.5) / 127.5).float()
     assert torch.equal(norm_table(), ref)
     assert float(ref[0]) == -1.0 and float(ref[255]) == 1.0
+
+
+def _bench(args, env_extra):
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    env.pop("WORLD_SIZE", None) if "WORLD_SIZE" not in env_extra else None
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus N` is what the driver runs: the process must start N ranks ITSELF (the flag used
+    to be parsed and ignored).  Dry run (no GPU): the ranks rendezvous over gloo and count themselves."""
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"SDM_BENCH_DRYRUN": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["ranks_counted"] == 2 and out["gpus_arg"] == 2
+    # an external launcher that disagrees with --gpus is an error, not a silently different job
+    r = _bench(["--gpus", "2"], {"SDM_BENCH_DRYRUN": "1", "WORLD_SIZE": "3", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+    # a failing rank fails the launcher (here: no GPU for the real run)
+    if not torch.cuda.is_available():
+        r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-configs", "--no-cpu-baseline"], {})
+        assert r.returncode != 0
+
+
+def test_dataset_record_order_is_rank_consistent_under_data_parallelism(tmp_path, monkeypatch):
+    """the conditional / doodle datasets shuffle their records at construction (as the reference does).  Under
+    WORLD_SIZE > 1 every rank builds its own dataset, and the samplers hand out index shards: the shards are disjoint and
+    cover the dataset only if the record order is the same on every rank, whatever each process's `random` state is."""
+    import random
+    from custom_dataset.img_dataset import ConditionalImgDataset, DoodleImgDataset
+    n = 24
+    db = {"Data": {str(i + 1): {"filename": f"im{i:02d}.png", "lab": f"lab{i:02d}.png", "a": float(i)} for i in range(n)},
+          "Labels": {"1": {"labels": ["lab", "a"]}}}
+    (tmp_path / "db.json").write_text(json.dumps(db))
+    dbc = {"Data": db["Data"], "Labels": {"1": {"labels": ["a"]}}}
+    (tmp_path / "dbc.json").write_text(json.dumps(dbc))
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    for cls, path in ((ConditionalImgDataset, "dbc.json"), (DoodleImgDataset, "db.json")):
+        per_rank = []
+        for rank in range(2):
+            random.seed(1000 + rank)                       # ranks are separate processes with unrelated `random` states
+            ds = cls(str(tmp_path / path))
+            sampler = torch.utils.data.distributed.DistributedSampler(ds, 2, rank, shuffle=True)
+            sampler.set_epoch(5)
+            per_rank.append({ds.dataset[i][0] for i in sampler})
+        assert len(per_rank[0]) == len(per_rank[1]) == n // 2
+        assert not (per_rank[0] & per_rank[1]) and len(per_rank[0] | per_rank[1]) == n
+    # one process: the reference's plain random.shuffle (seedable through `random`, and really shuffled)
+    monkeypatch.delenv("WORLD_SIZE")
+    random.seed(7)
+    a = [r[0] for r in ConditionalImgDataset(str(tmp_path / "dbc.json")).dataset]
+    random.seed(8)
+    b = [r[0] for r in ConditionalImgDataset(str(tmp_path / "dbc.json")).dataset]
+    assert sorted(a) == sorted(b) and a != b

@@ -162,16 +162,17 @@ def test_two_rank_step_equals_single_rank_standard_architecture(tmp_path):
 
 
 def test_bench_two_rank_rehearsal_reports_multi_gpu_fields(tmp_path):
-    """bench.py under WORLD_SIZE=2 (gloo rehearsal, both ranks on the one GPU; the driver launches the same command with
-    RCCL on 2/4/8 GPUs): the JSON line carries the multi-GPU readiness fields -- what the communicator sees (backend, ranks,
+    """`python bench.py --gpus 2` (gloo rehearsal, both ranks on the one GPU; the driver runs the same command with RCCL
+    on 2/4/8 GPUs): the JSON line carries the multi-GPU readiness fields -- what the communicator sees (backend, ranks,
     RCCL version), the bus bandwidth of one 64 MB bucket, the all-reduce exposed per step and BASELINE's scaling
     configuration (C4: 128x128, 32 images per GPU) as c4_steps_per_s."""
     import json
     import subprocess
     env = dict(os.environ, SDM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-                        "--warmup", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    env.pop("WORLD_SIZE", None)
+    # exactly the driver's command: no external launcher, bench.py starts the two ranks itself
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
@@ -179,6 +180,7 @@ def test_bench_two_rank_rehearsal_reports_multi_gpu_fields(tmp_path):
     m = out["multi_gpu"]
     assert m["nranks"] == 2 and m["backend"] == "gloo"
     for k in ("allreduce_64MB_ms", "allreduce_64MB_busGBps", "allreduce_exposed_ms", "step_ms_with_allreduce",
-              "step_ms_without_allreduce", "c4_ms_per_step", "c4_steps_per_s", "c4_images_per_s"):
+              "step_ms_without_allreduce", "c4_ms_per_step", "c4_steps_per_s", "c4_images_per_s", "c4_bf16_ms_per_step",
+              "c4_bf16_steps_per_s"):
         assert isinstance(m[k], float) and m[k] == m[k], k
     assert m["c4_steps_per_s"] > 0 and "cpu_baseline" not in out

@@ -177,3 +177,12 @@ def test_device_image_cache_matches_the_datasets_bit_for_bit(dev, tmp_path):
         seen.append(torch.cat([b[1][:, 1] for b in got]))
     both = torch.cat(seen).cpu()
     assert len(set((both * 10).round().int().tolist())) == 8          # 8 distinct images over the two ranks
+    # one process: a fresh permutation per epoch (cli_train calls set_epoch at every world size), the same
+    # permutation again for the same epoch
+    orders = {}
+    for ep in (0, 1, 1):
+        ld = CachedLoader(cc, 5, conditional=True)
+        ld.set_epoch(ep)
+        orders.setdefault(ep, []).append(torch.cat([b[1][:, 1] for b in ld]).cpu())
+    assert sorted(orders[0][0].tolist()) == sorted(orders[1][0].tolist()) and not torch.equal(orders[0][0], orders[1][0])
+    assert torch.equal(orders[1][0], orders[1][1])
