@@ -464,8 +464,13 @@ def checkpoint_case():
                                             "max_channel")})
     entry.update(image_recon=train_cfg["img_recon"], max_noise=train_cfg["max_noise_step"],
                  min_noise=train_cfg["min_noise_step"], noise_scheduler=train_cfg["noise_scheduler"])
+    # export_models.py:94-97: a BASE model's entry ALWAYS carries beta_1 / beta_T (copied from the training config's
+    # "beta1" / "betaT", create_diffusion_config.py:113-122 defaults), whatever the scheduler
+    entry.update(beta_1=5e-3, beta_T=9e-3)
     with open(os.path.join(d, "config.json"), "w") as f:
         json.dump({"models": [entry]}, f)
+    with open(os.path.join(d, "config_linear.json"), "w") as f:       # the same checkpoint exported with the LINEAR schedule
+        json.dump({"models": [dict(entry, noise_scheduler="LINEAR")]}, f)
     out = {}
     m.eval()
     x = torch.randn(2, 3, 8, 8, generator=g)
@@ -476,8 +481,84 @@ def checkpoint_case():
     x0, eps, t, lab, loss = step()
     out["x0"], out["eps"], out["t"], out["lab"], out["loss"] = x0.numpy(), eps.numpy(), t.numpy(), lab.numpy(), np.array(loss)
     _params_sample(m, out)
+    # what the reference generator does with config_linear.json (generate_images_diffusion.py:186-192, :232-254):
+    # NoiseDegradation(beta_1, beta_T, max_T) + DDIM from a fixed x_T with one label row broadcast over the batch.
+    # Uses the model as saved in diffusion_1.pt (one Adam step), drawn AFTER everything above: earlier vectors unchanged.
+    m2 = ref_model(cfg, {k: v.clone() for k, v in torch.load(os.path.join(d, "diffusion_1.pt"), weights_only=True)["model"].items()})
+    m2.eval()
+    lin = RD.NoiseDegradation(entry["beta_1"], entry["beta_T"], 1000, "cpu")
+    xT = torch.randn(2, 3, 8, 8, generator=g)
+    quiet = lambda *a, **k: None
+    out["lin_xT"] = xT.numpy()
+    out["lin_ddim_out"] = RS.ddim_sampling(m2, lin, 1 * xT, min_noise=1, max_noise=1000, cond_img=None,
+                                           labels_tensor=torch.tensor([1.0, 0.0]), ddim_step_size=250, log=quiet).detach().numpy()
     np.savez(os.path.join(HERE, "ref_checkpoint", "expected.npz"), **out)
     print("checkpoint case: resumed-step loss", loss)
+
+
+def dataset_case():
+    """SURVEY §8f rank 2 pin: the reference's OWN dataset classes (custom_dataset/img_dataset.py:19-36,
+    conditional_img_dataset.py:14-66, doodle_dataset.py:14-66) run here with `cv2` and `tinydb` stubbed -- neither is
+    installed, and neither does arithmetic: `cv2.imread` returns fixed uint8 BGR arrays (what a decoder hands over), the
+    TinyDB stub returns the tables' records in document order.  The normalisation, dtype conversions, permutation, label
+    handling and the initial shuffle are the reference's code.  Stored: the decoded bytes (inputs) and the tensors the
+    reference's __getitem__ returned (outputs)."""
+    import random
+    rng = np.random.default_rng(20240301)
+    n, H, W = 6, 8, 32
+    bgr = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    bgr[0] = (np.arange(H * W * 3) % 256).astype(np.uint8).reshape(H, W, 3)          # every byte value 0..255 occurs
+    lab = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    files = {f"/virtual/im{i}.png": bgr[i] for i in range(n)}
+    files.update({f"/virtual/lab{i}.png": lab[i] for i in range(n)})
+    cv2 = types.ModuleType("cv2")
+    cv2.imread = lambda path: files[path].copy()
+    recs = [{"filename": f"/virtual/im{i}.png", "doodle": f"/virtual/lab{i}.png", "smiling": i % 2, "hat": 0.25 * i}
+            for i in range(n)]
+    dbs = {"cond.json": {"Data": recs, "Labels": [{"labels": ["smiling", "hat"]}]},
+           "doodle.json": {"Data": recs, "Labels": [{"labels": ["doodle"]}]}}
+
+    class _Table(list):
+        def all(self):
+            return list(self)
+
+    class TinyDB:
+        def __init__(self, path):
+            self._db = dbs[os.path.basename(path)]
+
+        def table(self, name):
+            return _Table(dict(r) for r in self._db.get(name, []))
+
+    tinydb = types.ModuleType("tinydb")
+    tinydb.TinyDB = TinyDB
+    sys.modules["cv2"], sys.modules["tinydb"] = cv2, tinydb
+    try:
+        from custom_dataset.img_dataset import ImageDataset
+        from custom_dataset.conditional_img_dataset import ConditionalImgDataset
+        from custom_dataset.doodle_dataset import DoodleImgDataset
+        out = {"bgr_u8": bgr, "lab_u8": lab}
+        ds = ImageDataset([f"/virtual/im{i}.png" for i in range(n)])
+        out["img_out"] = np.stack([ds[i].numpy() for i in range(n)])
+        assert out["img_out"].dtype == np.float32
+        random.seed(123)
+        dc = ConditionalImgDataset("cond.json")
+        out["cond_order"] = np.array([int(p[len("/virtual/im"):-4]) for p, _ in dc.dataset])
+        items = [dc[i] for i in range(n)]
+        out["cond_img_out"] = np.stack([a.numpy() for a, _ in items])
+        out["cond_labels_out"] = np.stack([b.numpy() for _, b in items])
+        assert dc.get_labels() == ["smiling", "hat"]
+        random.seed(321)
+        dd = DoodleImgDataset("doodle.json")
+        out["doodle_order"] = np.array([int(p[len("/virtual/im"):-4]) for p, _ in dd.dataset])
+        items = [dd[i] for i in range(n)]
+        out["doodle_img_out"] = np.stack([a.numpy() for a, _ in items])
+        out["doodle_lab_out"] = np.stack([b.numpy() for _, b in items])
+        out["smiling"] = np.array([r["smiling"] for r in recs], dtype=np.float64)
+        out["hat"] = np.array([r["hat"] for r in recs], dtype=np.float64)
+    finally:
+        del sys.modules["cv2"], sys.modules["tinydb"]
+    np.savez(os.path.join(HERE, "datasets.npz"), **out)
+    print("dataset case: orders", out["cond_order"], out["doodle_order"])
 
 
 if __name__ == "__main__":
@@ -493,3 +574,5 @@ if __name__ == "__main__":
         cold_and_doodle_cases()
     if not which or "checkpoint" in which:
         checkpoint_case()
+    if not which or "datasets" in which:
+        dataset_case()

@@ -132,6 +132,49 @@ def test_reference_checkpoint_resume_and_generate(dev, O, tmp_path):
     assert imgs.shape == (2, 3, 8, 8) and bool(torch.isfinite(imgs).all())
     with pytest.raises(ValueError, match="labels"):
         generate_images_cold_diffusion(args[:-3] + ["--cold_step_size", "250"], log=quiet, save_locally=False)
+    # the LINEAR-schedule export (export_models.py:94-97 beta_1 / beta_T -> generate_images_diffusion.py:186-192): the
+    # generator runs from it, and DDIM under NoiseDegradation(beta_1, beta_T) from the fixture's x_T == the reference's
+    import diffusion_sampling_algorithms as S
+    args_l = ["-c", os.path.join(d, "config_linear.json")] + args[2:]
+    imgs = generate_images_diffusion(args_l + ["--diff_alg", "ddim", "--ddim_step_size", "250"], log=quiet, save_locally=False)
+    assert imgs.shape == (2, 3, 8, 8) and bool(torch.isfinite(imgs).all())
+    with open(os.path.join(d, "config_linear.json")) as f:
+        ml = json.load(f)["models"][0]
+    assert ml["noise_scheduler"] == "LINEAR"
+    net2 = U_Net(**{k: ml[v] for k, v in _UNET_KEYS.items()})
+    net2.load_state_dict(ck["model"], strict=True)
+    net2 = net2.cuda()
+    lin = D.NoiseDegradation(ml["beta_1"], ml["beta_T"], 1000, dev)
+    for graph in (True, False):
+        out = S.ddim_sampling(net2, lin, T(e["lin_xT"]).cuda(), 1, 1000, None, torch.tensor([1.0, 0.0]).cuda(), 250, dev, quiet,
+                              use_graph=graph)
+        assert rel(out, T(e["lin_ddim_out"])) < 5e-5, graph
+
+
+def test_device_image_cache_matches_the_reference_datasets_bit_for_bit(dev, tmp_path):
+    """f2 pin on the device: sdm_u8_gather_nchw (DeviceImageCache.batch) against tensors the REFERENCE's own datasets
+    returned (tests/golden/datasets.npz: custom_dataset/img_dataset.py:19-36, conditional_img_dataset.py:14-66 run with
+    cv2.imread / TinyDB stubbed as byte / record sources) -- plain, conditional (labels in the reference's shuffled record
+    order) and flipped (== torch.flip of the reference tensor on the width axis, train_diffusion.py:312-314)."""
+    import random
+    from test_oracle_golden import _write_dataset_files
+    from custom_dataset.device_cache import DeviceImageCache
+    from custom_dataset.img_dataset import open_dataset
+    g = np.load(os.path.join(GOLDEN, "datasets.npz"))
+    n = _write_dataset_files(tmp_path, g)
+    cache = DeviceImageCache(open_dataset(str(tmp_path / "im*.png"), False), dev)
+    assert torch.equal(cache.images.cpu(), T(g["bgr_u8"]))                     # the cache holds exactly the decoder's bytes
+    idx = torch.tensor([5, 0, 2, 2, 4, 1, 3], device=dev)
+    x, _ = cache.batch(idx)
+    assert torch.equal(x.cpu(), T(g["img_out"])[idx.cpu()])
+    flip = torch.tensor([1, 1, 0, 1, 0, 0, 1], device=dev, dtype=torch.bool)
+    xf, _ = cache.batch(idx, flip)
+    want = T(g["img_out"])[idx.cpu()]
+    assert torch.equal(xf.cpu(), torch.where(flip.cpu()[:, None, None, None], want.flip(-1), want))
+    random.seed(123)
+    cc = DeviceImageCache(open_dataset(str(tmp_path / "cond.json"), True, 2), dev)
+    xs, labs = cc.batch(torch.arange(n, device=dev))
+    assert torch.equal(xs.cpu(), T(g["cond_img_out"])) and torch.equal(labs.cpu(), T(g["cond_labels_out"]))
 
 
 def test_device_image_cache_matches_the_datasets_bit_for_bit(dev, tmp_path):

@@ -232,3 +232,53 @@ def test_reference_written_checkpoint_loads_strictly():
     with torch.no_grad():
         y = O.unet_forward({k: v for k, v in ck["model"].items()}, cfg, T(e["fwd_x"]), T(e["fwd_t"]), T(e["fwd_lab"]))
     assert torch.allclose(y, T(e["fwd_y"]), rtol=1e-4, atol=2e-6)
+    # export_models.py:94-97: BASE entries always carry beta_1 / beta_T; the LINEAR-schedule export of the same checkpoint
+    assert md["beta_1"] == 5e-3 and md["beta_T"] == 9e-3
+    with open(os.path.join(d, "config_linear.json")) as f:
+        ml = json.load(f)["models"][0]
+    assert ml["noise_scheduler"] == "LINEAR" and ml["model_name"] == md["model_name"]
+    with torch.no_grad():
+        out, _ = O.ddim_sample({k: v for k, v in ck["model"].items()}, cfg, O.LinearSchedule(ml["beta_1"], ml["beta_T"], 1000),
+                               T(e["lin_xT"]), 1, 1000, 250, labels=torch.tensor([1.0, 0.0]))
+    assert torch.allclose(out, T(e["lin_ddim_out"]), rtol=1e-4, atol=1e-5)
+
+
+def _write_dataset_files(tmp_path, g):
+    """The fixture's decoded bytes as lossless PNG files + the reference's TinyDB JSON layout."""
+    from PIL import Image
+    n = g["bgr_u8"].shape[0]
+    for i in range(n):
+        Image.fromarray(np.ascontiguousarray(g["bgr_u8"][i][:, :, ::-1])).save(tmp_path / f"im{i}.png")     # BGR -> RGB file
+        Image.fromarray(np.ascontiguousarray(g["lab_u8"][i][:, :, ::-1])).save(tmp_path / f"lab{i}.png")
+    data = {str(i + 1): {"filename": f"im{i}.png", "doodle": f"lab{i}.png", "smiling": int(g["smiling"][i]),
+                         "hat": float(g["hat"][i])} for i in range(n)}
+    (tmp_path / "cond.json").write_text(json.dumps({"_default": {}, "Data": data, "Labels": {"1": {"labels": ["smiling", "hat"]}}}))
+    (tmp_path / "doodle.json").write_text(json.dumps({"_default": {}, "Data": data, "Labels": {"1": {"labels": ["doodle"]}}}))
+    return n
+
+
+def test_datasets_match_the_reference_datasets_bit_for_bit(tmp_path):
+    """SURVEY §8f rank 2 pin (tests/golden/datasets.npz, make_golden.py dataset_case): tensors returned by the REFERENCE's
+    ImageDataset / ConditionalImgDataset / DoodleImgDataset.__getitem__ (their normalisation, conversions, label handling
+    and initial random.shuffle; cv2.imread / TinyDB stubbed as byte / record sources) == what the build's PIL + json
+    datasets return for the same decoded bytes, bit for bit, in the same (seeded) record order."""
+    import random
+    from custom_dataset.img_dataset import open_dataset, open_pair_dataset
+    g = load("datasets.npz")
+    n = _write_dataset_files(tmp_path, g)
+    ds = open_dataset(str(tmp_path / "im*.png"), False)
+    for i in range(n):
+        x = ds[i]
+        assert x.dtype == torch.float32 and x.is_contiguous() and torch.equal(x, T(g["img_out"][i]))
+    random.seed(123)
+    dc = open_dataset(str(tmp_path / "cond.json"), True, 2)
+    assert [int(os.path.basename(p)[2:-4]) for p, _ in dc.dataset] == g["cond_order"].tolist()
+    for i in range(n):
+        x, lab = dc[i]
+        assert torch.equal(x, T(g["cond_img_out"][i])) and torch.equal(lab, T(g["cond_labels_out"][i])) and lab.dtype == torch.float32
+    random.seed(321)
+    dd = open_pair_dataset(str(tmp_path / "doodle.json"))
+    assert [int(os.path.basename(p)[2:-4]) for p, _ in dd.dataset] == g["doodle_order"].tolist()
+    for i in range(n):
+        x, lab = dd[i]
+        assert torch.equal(x, T(g["doodle_img_out"][i])) and torch.equal(lab, T(g["doodle_lab_out"][i]))
