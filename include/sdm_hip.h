@@ -267,6 +267,18 @@ int sdm_col_softmax(float* scores, int batch, int S, int64_t lds, sdm_stream_t s
 /* backward: ds = scale * p * (dp - sum_i p*dp) per column, in place on dp. */
 int sdm_col_softmax_bwd(const float* p, float* dp, int batch, int S, int64_t lds, float scale, sdm_stream_t s);
 
+/* Attention core for short sequences (S <= 256 tokens, head width a multiple of 16; custom_layers.py:144-150), two launches
+ * on the exact-fp32 matrix cores for fp32 (bf16 = 0) or bf16 (bf16 = 1) rows.  qkv: [batch/heads * S][ld] rows with per-head
+ * [q | k | v] chunks of 3*dk (custom_layers.py:138-141); batch = images * heads.
+ *   sdm_attn_scores_small: P[b][i][j] = softmax over QUERIES i of (q_i . k_j) * scale -- one workgroup per 16 keys holds
+ *     the scores of all queries on chip, so neither the scores nor a separate softmax pass touch HBM; P [batch][S][ldp]
+ *     in the rows' type (bf16: columns [S, ldp) zero-filled, as sdm_col_softmax_bf16 leaves them);
+ *   sdm_attn_pv_small: res[i][head*dk + c] = sum_j P[b][i][j] v_j[c]   (V read k-major: no transpose copy). */
+int sdm_attn_scores_small(const void* qkv, int64_t ld, int batch, int S, int heads, int dk, float scale, void* P, int64_t ldp,
+                          int bf16, sdm_stream_t s);
+int sdm_attn_pv_small(const void* P, int64_t ldp, const void* qkv, int64_t ld, int batch, int S, int heads, int dk, void* res,
+                      int64_t ldr, int bf16, sdm_stream_t s);
+
 /* Sinusoidal timestep features (custom_layers.py:84-90): out[n][D] = [sin(t f_i) | cos(t f_i)]. t is int64;
  * freq[D/2] is the frequency table exp(-i ln(1e4)/(D/2-1)), computed once on the host exactly as the reference does. */
 int sdm_sinusoid(const int64_t* t, const float* freq, int n, int D, float* out, sdm_stream_t s);
@@ -311,14 +323,22 @@ int sdm_tanh_bwd(const float* dy, const float* y, float* dx, size_t n, sdm_strea
 /* Forward diffusion q(x_t|x_0) (degraders.py:51-59,96-104): xt = sqrt(ab[n]) x0 + sqrt(1-ab[n]) eps, NCHW. */
 int sdm_q_sample(const float* x0, const float* eps, const float* alpha_bar, float* xt, int images, size_t per_image,
                  sdm_stream_t s);
-/* DDPM reverse update (diffusion_sampling_algorithms.py:47-55). coef is a DEVICE array of 3 floats
+/* DDPM reverse update (diffusion_sampling_algorithms.py:42-55). coef is a DEVICE array of 3 floats
  * {1/sqrt(alpha_t), (1-alpha_t)/sqrt(1-abar_t), sigma_t} (device-resident so a captured graph can be replayed
- * with new coefficients); z may be NULL (last step). x is updated in place. */
-int sdm_ddpm_update(float* x, const float* eps, const float* z, const float* coef, size_t n, sdm_stream_t s);
+ * with new coefficients; sigma_t = 0 encodes the reference's z = 0 for noise_step <= 1). x is updated in place.
+ * Noise: `z` (injected, trajectory tests) or, with z == NULL and rng_step != NULL, drawn IN the kernel -- the reference's
+ * torch.randn_like(x_t) (:43) -- from Philox4x32-10 with counter {element/4 lo, hi, (uint32)*rng_step, 0} and key = seed,
+ * 4 normals per call by Box-Muller (SURVEY 8b "sdm_sampler_update_ddpm (fused elementwise + Philox)"); rng_step is a
+ * DEVICE word that differs from step to step and is stable during one (the sampler passes t_cur of sdm_step_begin);
+ * z == NULL and rng_step == NULL: no noise.  `cursor` (optional, DEVICE): the step cursor of sdm_step_begin, advanced here
+ * (saturating at nsteps) -- the step's last launch moves the captured graph on to the next table row. */
+int sdm_ddpm_update(float* x, const float* eps, const float* z, const float* coef, size_t n, unsigned long long seed,
+                    const int64_t* rng_step, int* cursor, int nsteps, sdm_stream_t s);
 /* DDIM update (diffusion_sampling_algorithms.py:111-136, eta=0): coef (DEVICE, 5 floats) = {1/sqrt(abar_t),
  * sqrt(1-abar_t), sqrt(abar_tm1), sqrt(1-abar_tm1), update_flag}.  x0_out (optional) receives the x0 estimate;
  * x is advanced to x_{t-1} only when update_flag != 0 (the reference skips the update on the last step). */
-int sdm_ddim_update(float* x, const float* eps, const float* coef, float* x0_out, size_t n, sdm_stream_t s);
+int sdm_ddim_update(float* x, const float* eps, const float* coef, float* x0_out, size_t n, int* cursor, int nsteps,
+                    sdm_stream_t s);   /* cursor: as in sdm_ddpm_update (optional) */
 
 /* Classifier-free guidance (build-side extension, BASELINE config 3; not in the reference): the U-Net is evaluated once
  * on a 2N batch [conditional | unconditional(all-zero label)]; out[i] = e_u[i] + w*(e_c[i] - e_u[i]). */
@@ -327,7 +347,9 @@ int sdm_cfg_combine(const float* eps_2n, float* out, float w, size_t n_half, sdm
 /* Cold-diffusion update of the super-resolution sampler (diffusion_sampling_algorithms.py:187-209):
  *   x <- x - (c0*x0 + c1*noise) + (c2*x0 + c3*noise),  coef (DEVICE, 5 floats) = {sqrt(abar_t), sqrt(1-abar_t),
  *   sqrt(abar_tm1), sqrt(1-abar_tm1), update_flag}; skipped when update_flag == 0 (last step). */
-int sdm_cold_update(float* x, const float* x0_hat, const float* noise, const float* coef, size_t n, sdm_stream_t s);
+int sdm_cold_update(float* x, const float* x0_hat, const float* noise, const float* coef, size_t n, float* x0_keep,
+                    int* cursor, int nsteps, sdm_stream_t s);   /* x0_keep (optional): copy of x0_hat kept for the caller
+                                                                  (the sampler's return value); cursor: as above */
 /* F.interpolate(mode="area") on NCHW fp32 == adaptive average pooling (train_SR_diffusion.py:321-328): output pixel
  * (i,j) averages input rows [floor(i*Hin/Hout), ceil((i+1)*Hin/Hout)) x the same for columns; integer
  * down-scaling is block averaging, integer up-scaling is pixel replication. */
@@ -341,13 +363,19 @@ int sdm_area_resize(const float* x, float* out, int planes, int Hin, int Win, in
 int sdm_u8_gather_nchw(const uint8_t* cache_nhwc, const int64_t* idx, const uint8_t* flip, const float* lut256,
                        float* out_nchw, int batch, int C, int H, int W, sdm_stream_t s);
 
-/* Step-table cursor for a hipGraph-captured sampling step: t_cur[0] = t_table[*cursor];
- * coef_cur[0..ncoef) = coef_table[*cursor][0..ncoef); ++*cursor (saturating at nsteps, reads clamp to the last row, so
- * *cursor - 1 is the index of the step in flight for all nsteps steps).  With it the captured
- * graph (advance -> U-Net forward -> update) is parameter-free and is simply replayed once per denoise step
- * (the python for-loops of diffusion_sampling_algorithms.py:21-63 and :91-145). */
-int sdm_step_advance(int* cursor, const int64_t* t_table, const float* coef_table, int ncoef, int nsteps,
-                     int64_t* t_cur, float* coef_cur, sdm_stream_t s);
+/* Head of a hipGraph-captured sampling step.  c = min(*cursor, nsteps-1) is the step being run (the cursor is READ
+ * here and advanced by the step's update kernel, sdm_ddpm/ddim/cold_update): t_cur[0] = t_table[c];
+ * coef_cur[0..ncoef) = coef_table[c][0..ncoef); and, with mod_time != NULL, the AdaGN modulation rows of the step
+ *   mods_cur[i][0..width) = mod_time[c][0..width) (+ mod_cond[i][0..width)),  i < rows
+ * from tables computed ONCE per sampling run: the time / label embedding MLPs and every y_scale projection
+ * (custom_layers.py:82-98, :40-44) depend on t and the labels only, and y_scale is linear, so
+ * W (te_t + ce_i) + b = (W te_t + b) + W ce_i.  With it the captured graph (begin -> U-Net convs -> update) is parameter-free
+ * and is replayed once per denoise step (the python for-loops of diffusion_sampling_algorithms.py:21-63, :91-145). */
+int sdm_step_begin(const int* cursor, const int64_t* t_table, const float* coef_table, int ncoef, int nsteps, int64_t* t_cur,
+                   float* coef_cur, const float* mod_time, const float* mod_cond, float* mods_cur, int rows, int width,
+                   sdm_stream_t s);
+/* ++*cursor (saturating at nsteps) as a launch of its own: steps whose update does not go through the kernels above. */
+int sdm_step_advance(int* cursor, int nsteps, sdm_stream_t s);
 
 /* Fused multi-tensor Adam (torch.optim.Adam defaults, train_diffusion.py:214-217): jobs is a DEVICE array. */
 typedef struct sdm_adam_job { float* p; const float* g; float* m; float* v; int64_t n; } sdm_adam_job;

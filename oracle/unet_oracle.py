@@ -308,6 +308,49 @@ def ddpm_sample(P, cfg, sched, x_t, noises, min_noise=1, max_noise=1000, labels=
     return x_t, traj
 
 
+# --------------------------------------------------------------------------- #
+# the DDPM step's noise as the HIP path draws it (sdm_ddpm_update): Philox4x32-10 + Box-Muller.
+# The reference draws torch.randn_like(x_t) (diffusion_sampling_algorithms.py:43) on whatever device it runs on; a CPU
+# and a GPU generator give different streams anyway, so the stream itself is not a parity quantity -- what is pinned
+# here is the generator (Random123's published known-answer vectors, tests/test_oracle_golden.py) and, against this
+# restatement, the kernel's bits -> normals mapping (tests/test_gpu_parity.py).
+# --------------------------------------------------------------------------- #
+def philox4x32_10(ctr, key):
+    """ctr: uint32 [..., 4], key: uint32 [..., 2] -> uint32 [..., 4] (Salmon et al., SC'11)."""
+    import numpy as np
+    c = [np.asarray(ctr[..., i], dtype=np.uint64) for i in range(4)]
+    k = [np.asarray(key[..., i], dtype=np.uint64) for i in range(2)]
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), \
+        np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k[0], p1 & MASK, (p0 >> np.uint64(32)) ^ c[3] ^ k[1], p0 & MASK]
+        k = [(k[0] + W0) & MASK, (k[1] + W1) & MASK]
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def philox_normal(seed, step, n):
+    """The n standard normals sdm_ddpm_update draws for (seed, step): element i comes from Philox counter
+    {i // 4 (lo, hi), step, 0}, key {seed lo, seed hi}; words (0, 1) and (2, 3) go through Box-Muller with
+    u1 = ((w >> 8) + 1) / 2^24, u2 = (w >> 8) / 2^24.  float64 arithmetic (the kernel's is float32)."""
+    import numpy as np
+    q = np.arange((n + 3) // 4, dtype=np.uint64)
+    ctr = np.stack([q & np.uint64(0xFFFFFFFF), q >> np.uint64(32), np.full_like(q, np.uint64(step & 0xFFFFFFFF)),
+                    np.zeros_like(q)], axis=-1)
+    key = np.broadcast_to(np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64), (q.shape[0], 2))
+    r = philox4x32_10(ctr, key).astype(np.float64)
+
+    def bm(a, b):
+        u1 = (np.floor(a / 256.0) + 1.0) / 16777216.0
+        u2 = np.floor(b / 256.0) / 16777216.0
+        rad = np.sqrt(-2.0 * np.log(u1))
+        return rad * np.cos(2.0 * np.pi * u2), rad * np.sin(2.0 * np.pi * u2)
+
+    z0, z1 = bm(r[:, 0], r[:, 1])
+    z2, z3 = bm(r[:, 2], r[:, 3])
+    return np.stack([z0, z1, z2, z3], axis=-1).reshape(-1)[:n]
+
+
 def ddim_steps(min_noise, max_noise, step):
     steps = list(range(max_noise, min_noise - 1, -step))
     if min_noise not in steps:

@@ -13,7 +13,7 @@ int sdm_set_error(int code, const char* fmt, ...) {
 
 unsigned long long g_sdm_launches = 0;
 
-extern "C" int sdm_version(void) { return 200; }
+extern "C" int sdm_version(void) { return 300; }
 
 extern "C" unsigned long long sdm_launch_count(void) { return g_sdm_launches; }
 

@@ -1,0 +1,224 @@
+// Attention core for SHORT sequences (S <= 256 tokens: the 16x16 / 8x8 / 4x4 feature maps of a 64x64 or 128x128 U-Net),
+// custom_layers.py:127-163 of the reference:
+//     scores = (q k^T) * d_k^-0.5 ; attn = softmax over the QUERY axis (dim=1, :147) ; res = attn v
+// At these sizes the three generic launches (scores GEMM [+ split-K finishing pass], column softmax, P.V GEMM [+ finishing
+// pass]; bf16 rows: + a V transpose) are pure fixed cost: 4 MFLOP of work behind ~40 us of dependent launches, four times
+// per denoise step.  Here the core is two launches, both on the exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32: 16-row
+// tiles, so a 16-token sequence wastes nothing), operands straight from global / L2 into MFMA fragments (no LDS staging:
+// every operand is a few hundred KB and each fragment is used by one wave), for fp32 or bf16 rows:
+//   attn_scores_small : one workgroup per block of 16 KEYS holds the scores of ALL queries against them (S x 16) in
+//                       accumulators, reduces max / sum over the queries on chip and writes the probabilities P once;
+//   attn_pv_small     : res tile (32 queries x 64 channels) = P[32 x S] V[S x 64], V read k-major (no transpose copy).
+// P has the layout of the generic path ([batch][S][ldp], fp32 or bf16 with zero-filled pad columns), so the training
+// backward (which keeps P) is unchanged.
+#include "sdm_common.h"
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ f32x4_t load4(const T* p);
+template <>
+__device__ __forceinline__ f32x4_t load4<float>(const float* p) {
+  return *(const f32x4_t*)p;
+}
+template <>
+__device__ __forceinline__ f32x4_t load4<bf16_t>(const bf16_t* p) {
+  const u16x4 v = *(const u16x4*)p;
+  f32x4_t r = {bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ float load1(const T* p);
+template <>
+__device__ __forceinline__ float load1<float>(const float* p) {
+  return *p;
+}
+template <>
+__device__ __forceinline__ float load1<bf16_t>(const bf16_t* p) {
+  return bf2f(*p);
+}
+template <typename T>
+__device__ __forceinline__ void store1(T* p, float v);
+template <>
+__device__ __forceinline__ void store1<float>(float* p, float v) {
+  *p = v;
+}
+template <>
+__device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float v) {
+  *p = f2bf(v);
+}
+
+#define AS_KB 16          // keys per workgroup
+#define AS_MAXS 256       // queries held on chip
+#define AS_WAVES 8
+
+// v_mfma_f32_16x16x4_f32: lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; D: col = l&15, row = 4*(l>>4) + reg.
+// Each lane loads 4 consecutive reduction elements (16 bytes of fp32, 8 of bf16) at k0 + 4*(l>>4) and feeds element s to
+// MFMA s: the same permutation of the reduction index on both operands, so the sum is unchanged.
+template <typename T>
+__global__ __launch_bounds__(64 * AS_WAVES) void attn_scores_small_kernel(const T* __restrict__ qkv, long long ld, int S, int heads,
+                                                                           int dk, float scale, T* __restrict__ P, long long ldp) {
+  __shared__ float xs[AS_MAXS][AS_KB + 1];            // scores of all queries against this block's keys
+  __shared__ float s_m[AS_KB], s_inv[AS_KB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, img = b / heads, head = b % heads;
+  const int j0 = blockIdx.x * AS_KB;
+  const T* qb = qkv + (long long)img * S * ld + (long long)head * 3 * dk;      // q chunk of this (image, head)
+  const T* kb = qb + dk;
+  const int mt = (S + 15) >> 4;                       // 16-query tiles
+  // work split over the 8 waves: tiles first, then slices of the reduction (head width)
+  int mtp = 1;
+  while (mtp < mt && mtp < AS_WAVES) mtp <<= 1;
+  int ksplit = AS_WAVES / mtp;
+  while (ksplit > 1 && (dk / ksplit) % 16 != 0) ksplit >>= 1;
+  const int tile0 = wave % mtp, ks = wave / mtp;
+  const bool active = ks < ksplit;
+  const int kper = dk / ksplit, kbeg = ks * kper;
+  const int li = lane & 15, kg = lane >> 4;
+
+  for (int e = tid; e < AS_MAXS * (AS_KB + 1); e += 64 * AS_WAVES) (&xs[0][0])[e] = 0.f;
+  __syncthreads();
+
+  if (active) {
+    const int key = min(j0 + li, S - 1);
+    const T* kp = kb + (long long)key * ld + kbeg + 4 * kg;
+    for (int t = tile0; t < mt; t += mtp) {
+      const int q = min(t * 16 + li, S - 1);
+      const T* qp = qb + (long long)q * ld + kbeg + 4 * kg;
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      int k = 0;
+      for (; k + 64 <= kper; k += 64) {        // four 16-deep steps per trip: eight loads in flight ahead of 16 MFMAs
+        f32x4_t a[4], bb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a[u] = load4<T>(qp + k + 16 * u);
+          bb[u] = load4<T>(kp + k + 16 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], bb[u][s], acc, 0, 0, 0);
+      }
+      for (; k < kper; k += 16) {
+        const f32x4_t a = load4<T>(qp + k), bb = load4<T>(kp + k);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bb[s], acc, 0, 0, 0);
+      }
+      // D: column (key) = li, rows (queries) = 4*kg + r
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&xs[t * 16 + 4 * kg + r][li], acc[r]);      // LDS add: folds the k-slices
+    }
+  }
+  __syncthreads();
+
+  // column softmax over the queries: 32 threads per key
+  const int key = tid >> 5, sub = tid & 31;
+  float m = -INFINITY;
+  for (int i = sub; i < S; i += 32) m = fmaxf(m, xs[i][key] * scale);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float l = 0.f;
+  for (int i = sub; i < S; i += 32) l += __expf(xs[i][key] * scale - m);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+  if (sub == 0) {
+    s_m[key] = m;
+    s_inv[key] = 1.f / l;
+  }
+  __syncthreads();
+  // P rows: 16 consecutive keys per query
+  T* pb = P + (long long)b * S * ldp;
+  for (int e = tid; e < S * AS_KB; e += 64 * AS_WAVES) {
+    const int i = e >> 4, jj = e & 15;
+    const int j = j0 + jj;
+    if (j < S) store1<T>(pb + (long long)i * ldp + j, __expf(xs[i][jj] * scale - s_m[jj]) * s_inv[jj]);
+    else if (j < ldp) store1<T>(pb + (long long)i * ldp + j, 0.f);      // reduction padding of P.V stays zero
+  }
+}
+
+// res[q][dd] = sum_j P[q][j] v[j][dd]; workgroup = 32 queries x 64 channels, wave = 16 queries x 32 channels
+template <typename T>
+__global__ __launch_bounds__(256) void attn_pv_small_kernel(const T* __restrict__ P, long long ldp, const T* __restrict__ qkv,
+                                                            long long ld, int S, int heads, int dk, T* __restrict__ res,
+                                                            long long ldr) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, img = b / heads, head = b % heads;
+  const int ndt = (dk + 63) >> 6;
+  const int qt = blockIdx.x / ndt, dt = blockIdx.x % ndt;
+  const int q0 = qt * 32 + (wave >> 1) * 16, d0 = dt * 64 + (wave & 1) * 32;
+  const int li = lane & 15, kg = lane >> 4;
+  if (q0 >= S || d0 >= dk) return;
+  const T* pb = P + (long long)b * S * ldp + (long long)min(q0 + li, S - 1) * ldp;
+  const T* vb = qkv + (long long)img * S * ld + (long long)head * 3 * dk + 2 * dk;
+  const int c0 = min(d0 + li, dk - 1), c1 = min(d0 + 16 + li, dk - 1);
+  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int Sk = (S + 15) & ~15;
+  for (int j = 0; j < Sk; j += 16) {
+    const int jj = j + 4 * kg;
+    f32x4_t a;
+    if (jj + 3 < S) {
+      a = load4<T>(pb + jj);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a[s] = jj + s < S ? load1<T>(pb + jj + s) : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const long long row = (long long)min(jj + s, S - 1) * ld;
+      const float v0 = load1<T>(vb + row + c0), v1 = load1<T>(vb + row + c1);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], v0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], v1, acc1, 0, 0, 0);
+    }
+  }
+  T* rb = res + ((long long)img * S) * ldr + (long long)head * dk;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = q0 + 4 * kg + r;
+    if (q >= S) continue;
+    if (d0 + li < dk) store1<T>(rb + (long long)q * ldr + d0 + li, acc0[r]);
+    if (d0 + 16 + li < dk) store1<T>(rb + (long long)q * ldr + d0 + 16 + li, acc1[r]);
+  }
+}
+
+static int attn_small_check(const void* qkv, int64_t ld, int batch, int S, int heads, int dk, const void* P, int64_t ldp,
+                            int elt) {
+  SDM_CHECK_ARG(qkv && P && batch > 0 && heads > 0 && batch % heads == 0, "attn_small: bad args");
+  SDM_CHECK_ARG(S > 0 && S <= AS_MAXS, "attn_small: S = %d (this path holds at most %d queries on chip)", S, AS_MAXS);
+  SDM_CHECK_ARG(dk > 0 && dk % 16 == 0, "attn_small: head width %d must be a multiple of 16", dk);
+  SDM_CHECK_ARG(ld >= 3LL * heads * dk && ldp >= S, "attn_small: row pitches");
+  SDM_CHECK_ARG((ld * elt) % 16 == 0 && (((uintptr_t)qkv) & 15) == 0 && (dk * elt) % 16 == 0 && (ldp * elt) % (4 * elt) == 0 &&
+                    (ldp % 4) == 0 && (((uintptr_t)P) & 15) == 0,
+                "attn_small: rows must be 16-byte aligned (pitch of qkv, head width, pitch of P a multiple of 4)");
+  return SDM_OK;
+}
+
+extern "C" int sdm_attn_scores_small(const void* qkv, int64_t ld, int batch, int S, int heads, int dk, float scale, void* P,
+                                     int64_t ldp, int bf16, sdm_stream_t s) {
+  int rc = attn_small_check(qkv, ld, batch, S, heads, dk, P, ldp, bf16 ? 2 : 4);
+  if (rc != SDM_OK) return rc;
+  dim3 grid(cdiv(bf16 ? (ldp < ((S + 15) & ~15) ? ldp : ((S + 15) & ~15)) : S, AS_KB), batch);
+  if (bf16)
+    hipLaunchKernelGGL(attn_scores_small_kernel<bf16_t>, grid, dim3(64 * AS_WAVES), 0, (hipStream_t)s, (const bf16_t*)qkv,
+                       (long long)ld, S, heads, dk, scale, (bf16_t*)P, (long long)ldp);
+  else
+    hipLaunchKernelGGL(attn_scores_small_kernel<float>, grid, dim3(64 * AS_WAVES), 0, (hipStream_t)s, (const float*)qkv,
+                       (long long)ld, S, heads, dk, scale, (float*)P, (long long)ldp);
+  SDM_CHECK_LAUNCH("attn_scores_small");
+  return SDM_OK;
+}
+
+extern "C" int sdm_attn_pv_small(const void* P, int64_t ldp, const void* qkv, int64_t ld, int batch, int S, int heads, int dk,
+                                 void* res, int64_t ldr, int bf16, sdm_stream_t s) {
+  int rc = attn_small_check(qkv, ld, batch, S, heads, dk, P, ldp, bf16 ? 2 : 4);
+  if (rc != SDM_OK) return rc;
+  SDM_CHECK_ARG(res && ldr >= (int64_t)heads * dk, "attn_pv_small: bad output");
+  dim3 grid(cdiv(S, 32) * cdiv(dk, 64), batch);
+  if (bf16)
+    hipLaunchKernelGGL(attn_pv_small_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)P, (long long)ldp,
+                       (const bf16_t*)qkv, (long long)ld, S, heads, dk, (bf16_t*)res, (long long)ldr);
+  else
+    hipLaunchKernelGGL(attn_pv_small_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)P, (long long)ldp,
+                       (const float*)qkv, (long long)ld, S, heads, dk, (float*)res, (long long)ldr);
+  SDM_CHECK_LAUNCH("attn_pv_small");
+  return SDM_OK;
+}

@@ -1055,22 +1055,85 @@ extern "C" int sdm_q_sample(const float* x0, const float* eps, const float* alph
   return SDM_OK;
 }
 
-__global__ void ddpm_update_kernel(float* x, const float* eps, const float* z, const float* coef, size_t n) {
-  const float s1 = coef[0], s2 = coef[1], sg = coef[2];
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    float v = s1 * (x[i] - s2 * eps[i]);
-    if (z) v += sg * z[i];
-    x[i] = v;
+// ---- sampler step tail: the update kernels also ADVANCE the step cursor (one launch fewer per step than a separate
+// advance kernel).  Every other read of *cursor in a step (sdm_step_begin, injected-noise lookups) is in a launch that
+// precedes the update on the stream; inside the update kernel ONLY block 0 / thread 0 touches the cursor (read, then
+// store), so no block can observe the new value -- anything the other blocks need per step (the Philox counter) comes
+// from a word that sdm_step_begin wrote and nobody rewrites during the step (`rng_step` = the timestep).
+__device__ __forceinline__ void cursor_advance(int* cursor, int nsteps) {
+  if (cursor && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int raw = *cursor;
+    *cursor = raw < nsteps ? raw + 1 : nsteps;
   }
 }
-extern "C" int sdm_ddpm_update(float* x, const float* eps, const float* z, const float* coef, size_t n, sdm_stream_t s) {
+
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the generator behind
+// torch.randn on GPUs): counter = {element block lo, hi, step, 0}, key = {seed lo, seed hi}.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// two uniform 32-bit words -> two standard normals (Box-Muller; u1 in (0, 1], u2 in [0, 1))
+__device__ __forceinline__ void box_muller(unsigned a, unsigned b, float& z0, float& z1) {
+  const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+  const float r = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincosf(6.28318530717958647692f * u2, &sn, &cs);
+  z0 = r * cs;
+  z1 = r * sn;
+}
+
+__global__ void ddpm_update_kernel(float* x, const float* eps, const float* z, const float* coef, size_t n,
+                                   unsigned long long seed, const long long* rng_step, int* cursor, int nsteps) {
+  const float s1 = coef[0], s2 = coef[1], sg = coef[2];
+  if (!z && rng_step && sg != 0.f) {
+    const unsigned step = (unsigned)*rng_step;
+    // z ~ N(0, I) in-kernel (diffusion_sampling_algorithms.py:43-48: torch.randn_like, zero when noise_step <= 1, which
+    // the coefficient table encodes as sigma = 0): 4 elements per Philox call
+    const size_t n4 = (n + 3) / 4;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (size_t)gridDim.x * 256) {
+      unsigned r[4];
+      philox4x32_10((unsigned)q, (unsigned)(q >> 32), step, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
+      float zz[4];
+      box_muller(r[0], r[1], zz[0], zz[1]);
+      box_muller(r[2], r[3], zz[2], zz[3]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const size_t i = q * 4 + k;
+        if (i < n) x[i] = s1 * (x[i] - s2 * eps[i]) + sg * zz[k];
+      }
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+      float v = s1 * (x[i] - s2 * eps[i]);
+      if (z) v += sg * z[i];
+      x[i] = v;
+    }
+  }
+  cursor_advance(cursor, nsteps);
+}
+extern "C" int sdm_ddpm_update(float* x, const float* eps, const float* z, const float* coef, size_t n,
+                               unsigned long long seed, const int64_t* rng_step, int* cursor, int nsteps, sdm_stream_t s) {
   SDM_CHECK_ARG(x && eps && coef && n > 0, "ddpm_update: bad args");
-  hipLaunchKernelGGL(ddpm_update_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, eps, z, coef, n);
+  SDM_CHECK_ARG(cursor == nullptr || nsteps > 0, "ddpm_update: cursor without nsteps");
+  hipLaunchKernelGGL(ddpm_update_kernel, dim3(ew_grid(rng_step && !z ? (n + 3) / 4 : n)), dim3(256), 0, (hipStream_t)s, x, eps, z,
+                     coef, n, seed, (const long long*)rng_step, cursor, nsteps);
   SDM_CHECK_LAUNCH("ddpm_update");
   return SDM_OK;
 }
 
-__global__ void ddim_update_kernel(float* x, const float* eps, const float* coef, float* x0_out, size_t n) {
+__global__ void ddim_update_kernel(float* x, const float* eps, const float* coef, float* x0_out, size_t n, int* cursor,
+                                   int nsteps) {
   const float inv = coef[0], sq1m = coef[1], sa1 = coef[2], sb1 = coef[3];
   const bool upd = coef[4] != 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -1079,10 +1142,13 @@ __global__ void ddim_update_kernel(float* x, const float* eps, const float* coef
     if (x0_out) x0_out[i] = x0;
     if (upd) x[i] = sa1 * x0 + sb1 * e;
   }
+  cursor_advance(cursor, nsteps);
 }
-extern "C" int sdm_ddim_update(float* x, const float* eps, const float* coef, float* x0_out, size_t n, sdm_stream_t s) {
+extern "C" int sdm_ddim_update(float* x, const float* eps, const float* coef, float* x0_out, size_t n, int* cursor, int nsteps,
+                               sdm_stream_t s) {
   SDM_CHECK_ARG(x && eps && coef && n > 0, "ddim_update: bad args");
-  hipLaunchKernelGGL(ddim_update_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, eps, coef, x0_out, n);
+  SDM_CHECK_ARG(cursor == nullptr || nsteps > 0, "ddim_update: cursor without nsteps");
+  hipLaunchKernelGGL(ddim_update_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, eps, coef, x0_out, n, cursor, nsteps);
   SDM_CHECK_LAUNCH("ddim_update");
   return SDM_OK;
 }
@@ -1100,18 +1166,26 @@ extern "C" int sdm_cfg_combine(const float* eps_2n, float* out, float w, size_t 
   return SDM_OK;
 }
 
-__global__ void cold_update_kernel(float* x, const float* x0, const float* nz, const float* coef, size_t n) {
+__global__ void cold_update_kernel(float* x, const float* x0, const float* nz, const float* coef, size_t n, float* x0_keep,
+                                   int* cursor, int nsteps) {
   const float a = coef[0], b = coef[1], c = coef[2], d = coef[3];
-  if (coef[4] == 0.f) return;
+  const bool upd = coef[4] != 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const float v0 = x0[i], e = nz[i];
-    x[i] = x[i] - (a * v0 + b * e) + (c * v0 + d * e);
+    const float v0 = x0[i];
+    if (x0_keep) x0_keep[i] = v0;
+    if (upd) {
+      const float e = nz[i];
+      x[i] = x[i] - (a * v0 + b * e) + (c * v0 + d * e);
+    }
   }
+  cursor_advance(cursor, nsteps);
 }
-extern "C" int sdm_cold_update(float* x, const float* x0_hat, const float* noise, const float* coef, size_t n,
-                               sdm_stream_t s) {
+extern "C" int sdm_cold_update(float* x, const float* x0_hat, const float* noise, const float* coef, size_t n, float* x0_keep,
+                               int* cursor, int nsteps, sdm_stream_t s) {
   SDM_CHECK_ARG(x && x0_hat && noise && coef && n > 0, "cold_update: bad args");
-  hipLaunchKernelGGL(cold_update_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, x0_hat, noise, coef, n);
+  SDM_CHECK_ARG(cursor == nullptr || nsteps > 0, "cold_update: cursor without nsteps");
+  hipLaunchKernelGGL(cold_update_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, x0_hat, noise, coef, n, x0_keep,
+                     cursor, nsteps);
   SDM_CHECK_LAUNCH("cold_update");
   return SDM_OK;
 }
@@ -1141,21 +1215,48 @@ extern "C" int sdm_area_resize(const float* x, float* out, int planes, int Hin, 
   return SDM_OK;
 }
 
-__global__ void step_advance_kernel(int* cursor, const int64_t* t_table, const float* coef_table, int ncoef, int nsteps,
-                                    int64_t* t_cur, float* coef_cur) {
+__global__ __launch_bounds__(256) void step_begin_kernel(const int* cursor, const int64_t* t_table, const float* coef_table,
+                                                         int ncoef, int nsteps, int64_t* t_cur, float* coef_cur,
+                                                         const float* mod_time, const float* mod_cond, float* mods_cur, int rows,
+                                                         int width) {
   const int raw = *cursor;
   const int c = raw < nsteps ? raw : nsteps - 1;      // reads stay inside the tables however often the step is replayed
-  if (threadIdx.x == 0) t_cur[0] = t_table[c];
-  if (threadIdx.x < ncoef) coef_cur[threadIdx.x] = coef_table[(long long)c * ncoef + threadIdx.x];
-  __syncthreads();
-  if (threadIdx.x == 0) *cursor = raw < nsteps ? raw + 1 : nsteps;   // cursor - 1 == index of the step being run
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) t_cur[0] = t_table[c];
+    if (threadIdx.x < ncoef) coef_cur[threadIdx.x] = coef_table[(long long)c * ncoef + threadIdx.x];
+  }
+  if (!mod_time) return;
+  // the step's AdaGN modulation rows out of the per-run tables: mods_cur[i][:] = mod_time[c][:] (+ mod_cond[i][:])
+  const int w4 = width >> 2;
+  const f32x4* tr = (const f32x4*)(mod_time + (long long)c * width);
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (long long)rows * w4; e += (long long)gridDim.x * 256) {
+    const int i = (int)(e / w4), k = (int)(e - (long long)i * w4);
+    f32x4 v = tr[k];
+    if (mod_cond) v += ((const f32x4*)(mod_cond + (long long)i * width))[k];
+    ((f32x4*)(mods_cur + (long long)i * width))[k] = v;
+  }
 }
-extern "C" int sdm_step_advance(int* cursor, const int64_t* t_table, const float* coef_table, int ncoef, int nsteps,
-                                int64_t* t_cur, float* coef_cur, sdm_stream_t s) {
+extern "C" int sdm_step_begin(const int* cursor, const int64_t* t_table, const float* coef_table, int ncoef, int nsteps,
+                              int64_t* t_cur, float* coef_cur, const float* mod_time, const float* mod_cond, float* mods_cur,
+                              int rows, int width, sdm_stream_t s) {
   SDM_CHECK_ARG(cursor && t_table && coef_table && t_cur && coef_cur && ncoef > 0 && ncoef <= 64 && nsteps > 0,
-                "step_advance: bad args");
-  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, cursor, t_table, coef_table, ncoef, nsteps,
-                     t_cur, coef_cur);
+                "step_begin: bad args");
+  SDM_CHECK_ARG(mod_time == nullptr || (mods_cur && rows > 0 && width > 0 && width % 4 == 0 && aligned16(mod_time) &&
+                                        aligned16(mods_cur) && (mod_cond == nullptr || aligned16(mod_cond))),
+                "step_begin: modulation tables need rows > 0, width %% 4 == 0 and 16-byte aligned buffers");
+  long long g = mod_time ? ((long long)rows * (width / 4) + 255) / 256 : 1;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(step_begin_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, cursor, t_table, coef_table, ncoef, nsteps,
+                     t_cur, coef_cur, mod_time, mod_cond, mods_cur, rows, width);
+  SDM_CHECK_LAUNCH("step_begin");
+  return SDM_OK;
+}
+
+/* test / eager helper: ++*cursor (saturating at nsteps) as its own launch */
+__global__ void step_advance_kernel(int* cursor, int nsteps) { cursor_advance(cursor, nsteps); }
+extern "C" int sdm_step_advance(int* cursor, int nsteps, sdm_stream_t s) {
+  SDM_CHECK_ARG(cursor && nsteps > 0, "step_advance: bad args");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, cursor, nsteps);
   SDM_CHECK_LAUNCH("step_advance");
   return SDM_OK;
 }

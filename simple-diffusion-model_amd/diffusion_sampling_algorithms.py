@@ -26,6 +26,10 @@ def _use_graph(flag):
     return os.environ.get("SDM_HIPGRAPH", "1") != "0"
 
 
+MOD_TABLE = [os.environ.get("SDM_MOD_TABLE", "1") != "0"]       # modulation tables per run (U_Net.modulation_tables)
+MOD_TABLE_MAX_BYTES = 1 << 30
+
+
 class _StepRunner:
     """Owns the static buffers of one sampling run and replays the captured step."""
 
@@ -42,29 +46,59 @@ class _StepRunner:
         self.nsteps, self.ncoef = len(t_steps), coef.shape[1]
         self.t_table = torch.tensor(t_steps, dtype=torch.int64, device=dev)
         self.coef_table = coef.to(torch.float32).contiguous().to(dev)
-        self.cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=dev)       # index of the step being run
         self.t_cur = torch.zeros(1, dtype=torch.int64, device=dev)
         self.coef_cur = torch.zeros(self.ncoef, dtype=torch.float32, device=dev)
         self.graph = None
         self.body = None
         self.use_graph = use_graph
+        # in-kernel noise of the DDPM update: Philox key drawn from torch's (seedable) default generator once per run
+        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        # AdaGN modulation of every step of the run, tabulated once (the embedding depends on t and the labels only)
+        self.mod_time = self.mod_cond = self.mods_cur = self.mod_views = None
+        lab = self.labels2 if cfg_scale is not None else labels
+        rows = 1 if (lab is None or lab.dim() == 1) else lab.shape[0]
+        tables = getattr(net, "modulation_tables", None)
+        if MOD_TABLE[0] and tables is not None and getattr(net, "cond_emb", None) is not None:
+            width = sum((a.y_scale.weight.shape[0] + 3) // 4 * 4 for a in net._adagns)
+            if width and 4 * width * (self.nsteps + 2 * rows) <= MOD_TABLE_MAX_BYTES:
+                with torch.no_grad():
+                    self.mod_time, self.mod_cond, cols = tables(self.t_table, lab)
+                rows = 1 if self.mod_cond is None else self.mod_cond.shape[0]
+                self.mods_cur = torch.empty((rows, width), dtype=torch.float32, device=dev)
+                self.mod_views = [self.mods_cur[:, c0:c1] for c0, c1 in cols]
 
-    def advance(self):
-        lib.call("sdm_step_advance", self.cursor.data_ptr(), self.t_table.data_ptr(), self.coef_table.data_ptr(), self.ncoef,
-                 self.nsteps, self.t_cur.data_ptr(), self.coef_cur.data_ptr(), ops._stream())
+    def begin(self):
+        """Head of the step: this step's t, update coefficients and modulation rows out of the per-run tables."""
+        mt = self.mod_time
+        lib.call("sdm_step_begin", self.cursor.data_ptr(), self.t_table.data_ptr(), self.coef_table.data_ptr(), self.ncoef,
+                 self.nsteps, self.t_cur.data_ptr(), self.coef_cur.data_ptr(), None if mt is None else mt.data_ptr(),
+                 None if self.mod_cond is None else self.mod_cond.data_ptr(),
+                 None if mt is None else self.mods_cur.data_ptr(), 0 if mt is None else self.mods_cur.shape[0],
+                 0 if mt is None else self.mods_cur.shape[1], ops._stream())
+
+    def _net(self, x, t, labels):
+        if self.mod_views is None:
+            return self.net(x, t, labels)
+        self.net._preset_mods = self.mod_views
+        try:
+            return self.net(x, t, labels)
+        finally:
+            self.net._preset_mods = None
 
     def eps(self):
         xin = self.x if self.cond_img is None else torch.cat((self.x, self.cond_img), dim=1)
         if self.cfg_scale is None:
-            return self.net(xin, self.t_cur, self.labels)
+            return self._net(xin, self.t_cur, self.labels)
         n = xin.shape[0]
-        e2 = self.net(torch.cat((xin, xin), dim=0), self.t_cur.expand(2 * n).contiguous(), self.labels2)
+        e2 = self._net(torch.cat((xin, xin), dim=0), self.t_cur.expand(2 * n).contiguous(), self.labels2)
         return ops.cfg_combine(e2, self.cfg_scale)
 
     def z(self):
+        """Injected per-step noise (trajectory tests), else None: the DDPM update draws it in the kernel."""
         if self.noise is None:
-            return torch.randn(self.x.shape, device=self.x.device)
-        idx = (self.cursor - 1).clamp_(min=0).to(torch.int64)        # cursor already advanced for this step (it runs to nsteps)
+            return None
+        idx = self.cursor.clamp(max=self.nsteps - 1).to(torch.int64)      # the update kernel advances the cursor afterwards
         return self.noise.index_select(0, idx)[0]
 
     def run(self, body, on_step):
@@ -117,9 +151,9 @@ def ddpm_sampling(diffusion_net, noise_degradation, x_t, min_noise=1, max_noise=
     r = _StepRunner(diffusion_net, x_t, steps, coef, cond_img, labels_tensor, noise, _use_graph(use_graph), cfg_scale)
 
     def body():
-        r.advance()
+        r.begin()
         e = r.eps()
-        ops.ddpm_update(r.x, e, r.z(), r.coef_cur)
+        ops.ddpm_update(r.x, e, r.z(), r.coef_cur, seed=r.seed, rng_step=r.t_cur, cursor=r.cursor, nsteps=r.nsteps)
 
     def on_step(i):
         printProgressBar(iteration=i, total=max_noise - min_noise, prefix='Iterations:', suffix='Complete', length=50, log=log)
@@ -151,8 +185,8 @@ def ddim_sampling(diffusion_net, noise_degradation, x_t, min_noise=1, max_noise=
     x0 = torch.empty_like(r.x)
 
     def body():
-        r.advance()
-        ops.ddim_update(r.x, r.eps(), r.coef_cur, x0_out=x0)
+        r.begin()
+        ops.ddim_update(r.x, r.eps(), r.coef_cur, x0_out=x0, cursor=r.cursor, nsteps=r.nsteps)
 
     def on_step(i):
         printProgressBar(iteration=max_noise - steps[i], total=max_noise - min_noise, prefix='Iterations:',
@@ -188,9 +222,8 @@ def cold_diffusion_sampling(diffusion_net, noise_degradation, x_t, noise, min_no
     x0_hat = torch.empty((x_t.shape[0], diffusion_net.out_channel) + tuple(x_t.shape[2:]), dtype=torch.float32, device=dev)
 
     def body():
-        r.advance()
-        x0_hat.copy_(r.eps())                                        # the net predicts x0 here
-        ops.cold_update(r.x, x0_hat, noise, r.coef_cur)
+        r.begin()
+        ops.cold_update(r.x, r.eps(), noise, r.coef_cur, x0_keep=x0_hat, cursor=r.cursor, nsteps=r.nsteps)   # the net predicts x0
 
     def on_step(i):
         if i < len(steps) - 1:

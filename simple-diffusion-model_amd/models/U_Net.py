@@ -141,10 +141,44 @@ class U_Net(nn.Module):
         if x.shape[2] % div or x.shape[3] % div:
             raise RuntimeError(f"H and W must be multiples of 2**num_layers = {div} (skip connections must align)")
 
+    def modulation_tables(self, t_steps, labels=None):
+        """AdaGN modulation of a whole sampling run, computed once: (time_part [T, W], cond_part [n, W] or None, column
+        ranges [(c0, c1)] per AdaGN in self._adagns order).  With emb = te_t + ce_i (custom_layers.py:92-98) and y_scale
+        linear (:40-44), the modulation of step t for image i is  W (te_t + ce_i) + b = time_part[t] + cond_part[i]:
+        time_part[t] = W te_t + b over all T steps of the run, cond_part[i] = W ce_i.  The per-step forward then skips the
+        sinusoid, both embedding MLPs and every y_scale projection (six launches of a ~100-launch step at batch 1);
+        sdm_step_begin gathers the step's rows.  Same arithmetic as the per-step path up to fp32 summation order."""
+        if self.cond_emb is None or not self._adagns:
+            return None
+        dev = next(self.parameters()).device
+        te = self.cond_emb.time_rows(t_steps.to(dev))
+        ce = None
+        if labels is not None and self.cond_emb.cond_layer is not None:
+            ce = self.cond_emb.cond_rows(labels.to(dev))
+        cols, off = [], 0
+        for a in self._adagns:
+            O = a.y_scale.weight.shape[0]
+            cols.append((off, off + O))
+            off += (O + 3) // 4 * 4                     # float4-aligned column ranges
+        A = torch.empty((te.shape[0], off), dtype=torch.float32, device=dev)
+        B = None if ce is None else torch.empty((ce.shape[0], off), dtype=torch.float32, device=dev)
+        for a, (c0, c1) in zip(self._adagns, cols):
+            ops.linear_rows(te, a.y_scale.weight, a.y_scale.bias, out=A[:, c0:c1])
+            if B is not None:
+                ops.linear_rows(ce, a.y_scale.weight, None, out=B[:, c0:c1])
+        return A, B, cols
+
     def _run(self, ctx, x, t, cond):
         x = x.to(torch.float32).contiguous()
         emb = None
-        if self.cond_emb is not None:
+        preset = getattr(self, "_preset_mods", None)
+        if preset is not None and not ctx.train and self.cond_emb is not None:
+            # a sampler tabulated the modulation of the whole run (modulation_tables) and sdm_step_begin has put this
+            # step's rows into `preset`: no embedding work in the step
+            emb = preset[0]                              # (only its presence matters to the blocks)
+            ctx.emb = emb
+            ctx.mods = dict(zip(self._adagns, preset))
+        elif self.cond_emb is not None:
             emb = self.cond_emb.run(ctx, t.to(x.device), None if cond is None else cond.to(x.device))
             if ctx.train and emb.shape[0] != x.shape[0]:
                 raise RuntimeError("training needs one timestep per image (t of shape [N])")

@@ -281,6 +281,19 @@ class ConditionalEmbedding(nn.Module):
             ctx.rec[self] = rec
         return emb
 
+    def time_rows(self, t):
+        """time_layer(sinusoid(t)) for a vector of timesteps -> [len(t), D] (one row per sampling step: the samplers
+        tabulate the embedding of a whole run once, custom_layers.py:82-95 depends on t only)."""
+        t = t.reshape(-1).to(torch.int64).contiguous()
+        return self._mlp(self.time_layer, ops.sinusoid(t, self._freq, self.time_dim), None, None, "time")
+
+    def cond_rows(self, cond):
+        """cond_layer(cond) -> [n, D] (custom_layers.py:96-98 without the time addend)."""
+        c = cond.to(torch.float32)
+        if c.dim() == 1:
+            c = c[None, :]
+        return self._mlp(self.cond_layer, c.contiguous(), None, None, "cond")
+
     @staticmethod
     def _mlp(layers, x, add, rec, tag):
         xs, zs = [x], []

@@ -104,6 +104,8 @@ _PROTOS = {
                               fp, fp, fp, fp, fp, fp]),
     "sdm_col_softmax": (_i, [fp, _i, _i, _i64, fp]),
     "sdm_col_softmax_bwd": (_i, [fp, fp, _i, _i, _i64, _f, fp]),
+    "sdm_attn_scores_small": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, _i64, _i, fp]),
+    "sdm_attn_pv_small": (_i, [fp, _i64, fp, _i64, _i, _i, _i, _i, fp, _i64, _i, fp]),
     "sdm_sinusoid": (_i, [fp, fp, _i, _i, fp, fp]),
     "sdm_linear_small": (_i, [fp, _i64, fp, fp, fp, _i64, _i, fp, _i64, fp, _i, _i, _i, _i, fp]),
     "sdm_linear_multi": (_i, [fp, _i64, _i, _i, fp, _i, _i, fp]),
@@ -116,12 +118,13 @@ _PROTOS = {
     "sdm_mse": (_i, [fp, fp, fp, fp, _sz, fp]),
     "sdm_tanh_bwd": (_i, [fp, fp, fp, _sz, fp]),
     "sdm_q_sample": (_i, [fp, fp, fp, fp, _i, _sz, fp]),
-    "sdm_ddpm_update": (_i, [fp, fp, fp, fp, _sz, fp]),
-    "sdm_ddim_update": (_i, [fp, fp, fp, fp, _sz, fp]),
+    "sdm_ddpm_update": (_i, [fp, fp, fp, fp, _sz, C.c_ulonglong, fp, fp, _i, fp]),
+    "sdm_ddim_update": (_i, [fp, fp, fp, fp, _sz, fp, _i, fp]),
     "sdm_cfg_combine": (_i, [fp, fp, _f, _sz, fp]),
-    "sdm_cold_update": (_i, [fp, fp, fp, fp, _sz, fp]),
+    "sdm_cold_update": (_i, [fp, fp, fp, fp, _sz, fp, fp, _i, fp]),
     "sdm_area_resize": (_i, [fp, fp, _i, _i, _i, _i, _i, fp]),
-    "sdm_step_advance": (_i, [fp, fp, fp, _i, _i, fp, fp, fp]),
+    "sdm_step_begin": (_i, [fp, fp, fp, _i, _i, fp, fp, fp, fp, fp, _i, _i, fp]),
+    "sdm_step_advance": (_i, [fp, _i, fp]),
     "sdm_u8_gather_nchw": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "sdm_adam_multi": (_i, [fp, _i, _i64, _f, _f, _f, _f, _f, _f, _f, fp, fp]),
     # bf16 storage path (forward / sampling)

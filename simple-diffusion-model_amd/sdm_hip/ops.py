@@ -499,12 +499,34 @@ def _pad4(s):
     return (s + 3) // 4 * 4
 
 
+SMALL_ATTN = [os.environ.get("SDM_SMALL_ATTN", "1") != "0"]     # short sequences: the two-launch core of sdm_attn.hip
+SMALL_ATTN_MAX_S = 256
+
+
+def _small_attn_ok(qkv, S, dk):
+    return SMALL_ATTN[0] and S <= SMALL_ATTN_MAX_S and dk % 16 == 0 and qkv.stride(0) % 8 == 0
+
+
+def attention_core_small(qkv, n, S, heads, dk, Sp):
+    """Attention core of a short sequence in two launches (scores + column softmax on chip; P.V): returns (res, P) in the
+    rows' type with P laid out [n*heads, S, Sp] exactly as the generic path leaves it (the training backward keeps it)."""
+    dev, bf = qkv.device, int(qkv.dtype == BF16)
+    P = torch.empty((n * heads, S, Sp), dtype=qkv.dtype, device=dev)
+    res = torch.empty((n * S, heads * dk), dtype=qkv.dtype, device=dev)
+    st = _stream()
+    lib.call("sdm_attn_scores_small", _p(qkv), qkv.stride(0), n * heads, S, heads, dk, float(dk) ** -0.5, _p(P), Sp, bf, st)
+    lib.call("sdm_attn_pv_small", _p(P), Sp, _p(qkv), qkv.stride(0), n * heads, S, heads, dk, _p(res), res.stride(0), bf, st)
+    return res, P
+
+
 def attention_core_fwd(qkv, n, S, heads, dk):
     """qkv: [n*S, heads*3*dk] with per-head [q|k|v] chunks (custom_layers.py:138-141).
     Returns (res [n*S, heads*dk], P [n*heads, S, Sp]) with P the column-softmaxed scores."""
     dev = qkv.device
     Sp = _pad4(S)
     ld = qkv.stride(0)
+    if _small_attn_ok(qkv, S, dk):
+        return attention_core_small(qkv, n, S, heads, dk, Sp)
     P = torch.empty((n * heads, S, Sp), dtype=torch.float32, device=dev)
     d = _base_desc(S, S, dk)
     d.batch, d.bdiv = n * heads, heads
@@ -545,6 +567,9 @@ def attention_core_fwd_bf16(qkv, n, S, heads, dk, keep_p=False):
     dev = qkv.device
     Sp = _pad8(S)
     ld = qkv.stride(0)
+    if _small_attn_ok(qkv, S, dk):
+        res, P = attention_core_small(qkv, n, S, heads, dk, Sp)
+        return (res, P) if keep_p else res
     scores = torch.empty((n * heads, S, Sp), dtype=torch.float32, device=dev)
     d = _base_desc(S, S, dk)
     d.batch, d.bdiv = n * heads, heads
@@ -946,12 +971,15 @@ def q_sample(x0, eps, alpha_bar):
     return xt
 
 
-def ddpm_update(x, eps, z, coef):
-    lib.call("sdm_ddpm_update", _p(x), _p(eps), _p(z), _p(coef), x.numel(), _stream())
+def ddpm_update(x, eps, z, coef, seed=0, rng_step=None, cursor=None, nsteps=0):
+    """z: injected noise or None; rng_step (device int64 word, e.g. the step's t_cur): draw z in the kernel (Philox);
+    cursor: the sampler's step cursor, advanced by this launch."""
+    lib.call("sdm_ddpm_update", _p(x), _p(eps), _p(z), _p(coef), x.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(rng_step), _p(cursor),
+             nsteps, _stream())
 
 
-def ddim_update(x, eps, coef, x0_out=None):
-    lib.call("sdm_ddim_update", _p(x), _p(eps), _p(coef), _p(x0_out), x.numel(), _stream())
+def ddim_update(x, eps, coef, x0_out=None, cursor=None, nsteps=0):
+    lib.call("sdm_ddim_update", _p(x), _p(eps), _p(coef), _p(x0_out), x.numel(), _p(cursor), nsteps, _stream())
 
 
 def cfg_combine(eps_2n, w):
@@ -962,8 +990,8 @@ def cfg_combine(eps_2n, w):
     return out
 
 
-def cold_update(x, x0_hat, noise, coef):
-    lib.call("sdm_cold_update", _p(x), _p(x0_hat), _p(noise), _p(coef), x.numel(), _stream())
+def cold_update(x, x0_hat, noise, coef, x0_keep=None, cursor=None, nsteps=0):
+    lib.call("sdm_cold_update", _p(x), _p(x0_hat), _p(noise), _p(coef), x.numel(), _p(x0_keep), _p(cursor), nsteps, _stream())
 
 
 def area_resize(x, size):

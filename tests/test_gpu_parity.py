@@ -892,3 +892,175 @@ def test_modulation_bank_small_and_large_batch(dev, L, m):
         ref = emb @ l.weight.detach().t() + l.bias.detach()
         assert v.shape == ref.shape
         assert rel(v, ref) < 2e-6, rel(v, ref)
+
+
+def test_ddpm_update_draws_philox_normals_and_advances_the_cursor(dev, O):
+    """SURVEY 8b "sdm_sampler_update_ddpm (fused elementwise + Philox)": with x = eps = 0 and coef = {1, 0, 1} the update
+    writes its in-kernel z; it must equal the oracle's Philox4x32-10 + Box-Muller restatement (pinned on CPU by Random123's
+    known answers) for the same (seed, step word), for element counts that are not multiples of 4; sigma = 0 (the
+    reference's z = 0 for noise_step <= 1) leaves x deterministic; the launch advances the step cursor, saturating."""
+    from sdm_hip import ops
+    seed = 0x0123_4567_89ab_cdef
+    cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+    for n, step in ((4099, 1000), (12288, 2), (7, 123456789)):
+        x = torch.zeros(n, device=dev)
+        e = torch.zeros(n, device=dev)
+        coef = torch.tensor([1.0, 0.0, 1.0], device=dev)
+        st = torch.tensor([step], dtype=torch.int64, device=dev)
+        ops.ddpm_update(x, e, None, coef, seed=seed, rng_step=st, cursor=cursor, nsteps=2)
+        want = torch.from_numpy(O.philox_normal(seed, step, n)).float()
+        assert torch.allclose(x.cpu(), want, rtol=1e-4, atol=2e-5), float((x.cpu() - want).abs().max())
+    assert int(cursor) == 2                                               # three launches, saturating at nsteps = 2
+    x = torch.full((1000,), 2.0, device=dev)
+    e = torch.full((1000,), 0.5, device=dev)
+    ops.ddpm_update(x, e, None, torch.tensor([3.0, 2.0, 0.0], device=dev), seed=seed, rng_step=st)      # sigma = 0
+    assert torch.equal(x.cpu(), torch.full((1000,), 3.0))
+    x = torch.full((1000,), 2.0, device=dev)
+    ops.ddpm_update(x, e, None, torch.tensor([3.0, 2.0, 5.0], device=dev))                              # no rng word: no noise
+    assert torch.equal(x.cpu(), torch.full((1000,), 3.0))
+    z = torch.randn(1000, device=dev)
+    x = torch.full((1000,), 2.0, device=dev)
+    ops.ddpm_update(x, e, z, torch.tensor([3.0, 2.0, 5.0], device=dev), seed=seed, rng_step=st)         # injected z wins
+    assert torch.allclose(x, 3.0 + 5.0 * z, rtol=1e-5, atol=1e-5)
+
+
+def test_step_begin_gathers_the_modulation_rows(dev):
+    from sdm_hip import lib, ops
+    T_, rows, width, ncoef = 5, 3, 24, 3
+    g = torch.Generator().manual_seed(3)
+    tt = torch.tensor([900, 700, 500, 300, 1], dtype=torch.int64, device=dev)
+    coef = torch.randn(T_, ncoef, generator=g).to(dev)
+    A, B = torch.randn(T_, width, generator=g).to(dev), torch.randn(rows, width, generator=g).to(dev)
+    cur = torch.zeros(1, dtype=torch.int32, device=dev)
+    t_cur = torch.zeros(1, dtype=torch.int64, device=dev)
+    c_cur = torch.zeros(ncoef, device=dev)
+    mods = torch.zeros(rows, width, device=dev)
+    for c in (0, 3, 4, 9):                                                # 9: clamped to the last row
+        cur.fill_(c)
+        lib.call("sdm_step_begin", cur.data_ptr(), tt.data_ptr(), coef.data_ptr(), ncoef, T_, t_cur.data_ptr(), c_cur.data_ptr(),
+                 A.data_ptr(), B.data_ptr(), mods.data_ptr(), rows, width, ops._stream())
+        cc = min(c, T_ - 1)
+        assert int(t_cur) == int(tt[cc]) and torch.equal(c_cur, coef[cc]) and int(cur) == c
+        assert torch.equal(mods, A[cc][None, :] + B)
+        lib.call("sdm_step_begin", cur.data_ptr(), tt.data_ptr(), coef.data_ptr(), ncoef, T_, t_cur.data_ptr(), c_cur.data_ptr(),
+                 A.data_ptr(), None, mods.data_ptr(), 1, width, ops._stream())
+        assert torch.equal(mods[0], A[cc])
+    lib.call("sdm_step_advance", cur.data_ptr(), T_, ops._stream())
+    assert int(cur) == T_
+
+
+@pytest.mark.parametrize("labels_kind", ["none", "row", "per_image", "cfg"])
+def test_modulation_tables_equal_the_per_step_embedding(dev, O, labels_kind):
+    """The samplers tabulate the AdaGN modulation of a whole run once (U_Net.modulation_tables: W te_t + b and W ce_i, the
+    y_scale projection being linear) instead of running the embedding MLPs and the projections in every step
+    (custom_layers.py:82-98, :40-44).  Same samples as the per-step path, for every way labels reach the samplers:
+    none (label-free net), one label row broadcast over the batch (generate_images_diffusion.py:183), per-image labels
+    (the trainers' checkpoint plots), classifier-free guidance (2N rows)."""
+    import degraders as D
+    import diffusion_sampling_algorithms as S
+    from models.U_Net import U_Net
+    if labels_kind == "none":
+        cfg = O.full_cfg(dict(NARROW, cond_dim=None))
+        net = U_Net(**cfg)
+        net.load_state_dict(O.seeded_params(cfg, seed=3, gain=1.8), strict=True)
+        net = net.cuda()
+    else:
+        cfg, net = narrow_net(O)
+    g = torch.Generator().manual_seed(9)
+    xT = torch.randn(3, 3, 16, 16, generator=g).cuda()
+    lab = {"none": None, "row": torch.tensor([0.0, 1.0, 0.0]).cuda(), "per_image": torch.eye(3)[[2, 0, 1]].cuda(),
+           "cfg": torch.eye(3)[[2, 0, 1]].cuda()}[labels_kind]
+    kw = dict(cfg_scale=2.0) if labels_kind == "cfg" else {}
+    quiet = lambda *a, **k: None
+    sch = D.CosineNoiseDegradation(1000)
+    outs = {}
+    for table in (True, False):
+        S.MOD_TABLE[0] = table
+        try:
+            for graph in (True, False):
+                outs[(table, graph)] = S.ddim_sampling(net, sch, xT, 1, 1000, None, lab, 200, "cuda", quiet, use_graph=graph, **kw)
+        finally:
+            S.MOD_TABLE[0] = True
+    ref = outs[(False, False)]
+    for k, v in outs.items():
+        assert rel(v, ref) < 2e-6, (k, rel(v, ref))
+    # the table path must not run the embedding per step: fewer library launches per step
+    from sdm_hip import lib
+    counts = {}
+    for table in (True, False):
+        S.MOD_TABLE[0] = table
+        try:
+            l0 = lib.launch_count()
+            S.ddim_sampling(net, sch, xT, 1, 1000, None, lab, 100, "cuda", quiet, use_graph=False, **kw)
+            counts[table] = lib.launch_count() - l0
+        finally:
+            S.MOD_TABLE[0] = True
+    if labels_kind != "none" or True:
+        assert counts[True] < counts[False], counts
+
+
+def test_ddpm_sampling_is_seedable_and_noise_is_fresh_per_step(dev, O):
+    """torch.manual_seed(s) makes a DDPM run reproducible (the Philox key is drawn from torch's default generator), other
+    seeds give other samples, graph replay == eager launching bit for bit, and the per-step noise really differs from
+    step to step (a stuck counter word would add the same z every step)."""
+    import degraders as D
+    import diffusion_sampling_algorithms as S
+    cfg, net = narrow_net(O)
+    xT = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(4)).cuda()
+    lab = torch.tensor([1.0, 0.0, 0.0]).cuda()
+    sch = D.CosineNoiseDegradation(1000)
+    quiet = lambda *a, **k: None
+
+    def run(seed, graph, hi=8):
+        torch.manual_seed(seed)
+        return S.ddpm_sampling(net, sch, xT, 1, hi, None, lab, "cuda", quiet, use_graph=graph)
+    a, b, c, d = run(11, True), run(11, True), run(11, False), run(12, True)
+    assert torch.equal(a, b) and torch.equal(a, c) and not torch.allclose(a, d)
+    # injected zeros == what the in-kernel path would give with sigma = 0: the difference is the noise the kernel added
+    z0 = torch.zeros(8, 2, 3, 16, 16)
+    det = S.ddpm_sampling(net, sch, xT, 1, 8, None, lab, "cuda", quiet, noise=z0, use_graph=True)
+    assert float((a - det).abs().mean()) > 1e-3
+
+
+@pytest.mark.parametrize("n,S,heads,dk", [(1, 16, 1, 1024), (2, 64, 1, 512), (1, 256, 1, 512), (3, 35, 2, 16), (2, 100, 3, 48),
+                                          (1, 255, 1, 64)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_short_sequence_attention_core(dev, n, S, heads, dk, bf16):
+    """sdm_attn_scores_small + sdm_attn_pv_small (S <= 256: scores and the softmax over QUERIES, custom_layers.py:144-150,
+    stay on chip) against a float64 torch computation on the same (bf16-rounded) rows, and against the generic three-launch
+    path they replace; ragged S, several heads, both row types.  x12 logits: softmax far from uniform."""
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(S * 7 + dk)
+    qkv = torch.randn(n * S, heads * 3 * dk, generator=g)
+    qkv[:, :] *= 1.0
+    q_gain = 12.0 / dk ** 0.25
+    v = qkv.view(n, S, heads, 3, dk)
+    v[:, :, :, 0] *= q_gain
+    v[:, :, :, 1] *= q_gain
+    x = qkv.to(dev)
+    if bf16:
+        x = x.to(torch.bfloat16)
+    xr = x.double().view(n, S, heads, 3, dk).cpu()
+    q, k, vv = xr[:, :, :, 0], xr[:, :, :, 1], xr[:, :, :, 2]
+    sc = torch.einsum("nihd,njhd->nijh", q, k) * dk ** -0.5
+    attn = sc.softmax(dim=1)
+    want = torch.einsum("nijh,njhd->nihd", attn, vv).reshape(n * S, heads * dk)
+    Sp = ops._pad8(S) if bf16 else ops._pad4(S)
+    assert ops._small_attn_ok(x, S, dk)
+    res, P = ops.attention_core_small(x, n, S, heads, dk, Sp)
+    tolP, tolR = (8e-3, 8e-3) if bf16 else (2e-5, 2e-5)
+    Pw = attn.permute(0, 3, 1, 2).reshape(n * heads, S, S)
+    assert rel(P[:, :, :S].float(), Pw) < tolP, rel(P[:, :, :S].float(), Pw)
+    assert rel(res.float(), want) < tolR, rel(res.float(), want)
+    if bf16:
+        assert float(P[:, :, S:].float().abs().max()) == 0.0 if Sp > S else True        # reduction padding stays zero
+    ops.SMALL_ATTN[0] = False
+    try:
+        if bf16:
+            res2, P2 = ops.attention_core_fwd_bf16(x, n, S, heads, dk, keep_p=True)
+        else:
+            res2, P2 = ops.attention_core_fwd(x, n, S, heads, dk)
+    finally:
+        ops.SMALL_ATTN[0] = True
+    assert rel(res.float(), res2.float()) < (1.5e-2 if bf16 else 2e-5)
+    assert P2.shape == P.shape and P2.dtype == P.dtype

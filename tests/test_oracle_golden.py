@@ -282,3 +282,20 @@ def test_datasets_match_the_reference_datasets_bit_for_bit(tmp_path):
     for i in range(n):
         x, lab = dd[i]
         assert torch.equal(x, T(g["doodle_img_out"][i])) and torch.equal(lab, T(g["doodle_lab_out"][i]))
+
+
+def test_philox_known_answers_and_normal_moments():
+    """Philox4x32-10 (the generator sdm_ddpm_update draws the DDPM step's z from) against the three known-answer vectors
+    published with Random123 (kat_vectors: philox4x32 10), and the Box-Muller normals' first moments."""
+    def h(*a):
+        return np.array(a, dtype=np.uint32)[None]
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kats:
+        assert [int(v) for v in O.philox4x32_10(h(*ctr), h(*key))[0]] == list(want)
+    z = O.philox_normal(0x1234_5678_9abc_def0, 977, 1 << 18)
+    assert abs(z.mean()) < 1e-2 and abs(z.std() - 1) < 1e-2 and abs((z ** 4).mean() - 3) < 0.1 and abs((z ** 3).mean()) < 0.05
+    assert not np.allclose(z[:64], O.philox_normal(0x1234_5678_9abc_def0, 978, 64))          # another step: another stream
+    assert np.array_equal(z[:999], O.philox_normal(0x1234_5678_9abc_def0, 977, 999))          # prefix-stable in n
