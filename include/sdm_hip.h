@@ -148,6 +148,20 @@ typedef struct sdm_igemm_desc {
                              (SURVEY §7 step 5).  Done only for an unsplit plain 3x3 stride-1 conv whose tiles lie inside
                              one image; the call then returns SDM_STATS_DONE and sdm_gn_finalize turns the sums into the
                              affine tables; otherwise the sums stay untouched (zero) and the caller runs sdm_gn_affine_bf16. */
+  /* ---- sdm_igemm_bf16 only: the two-pass column softmax of attention (custom_layers.py:144-150: softmax over the QUERY
+   * axis, i.e. down the columns of scores = q k^T) without the S x S score matrix in HBM.  Same GEMM twice:
+   *   pass 1, col_stats != NULL: nothing is stored to `out`; for every M-tile t of the grid and column j the epilogue
+   *     writes the partial statistics of v = alpha * acc over the tile's rows,  col_stats[b][t][j] = {max_i v, sum_i
+   *     exp(v - max)}  (fp32 pairs, batch stride col_stats_bs floats; sdm_attn_colstats_combine folds the tiles);
+   *   pass 2, col_shift / col_mul != NULL: v = act(alpha * acc + col_shift[b][j]) * col_mul[b][j] with act =
+   *     SDM_ACT_EXP, i.e. exp(s - m_j) / l_j written once, as bf16 probabilities.
+   * Per-column vectors are fp32 [batch][N] with batch stride colvec_bs.  The product alpha * acc is ROUNDED to fp32 before
+   * the shift in both passes (no fma contraction), so pass 2 sees exactly the values pass 1 took its maxima from. */
+  float* col_stats;
+  int64_t col_stats_bs;
+  const float* col_shift;
+  const float* col_mul;
+  int64_t colvec_bs;
   int defer_epilogue;     /* 1: if the library splits K, it leaves the RAW sums in ws ([out row][N], alpha / bias / act not yet
                              applied) and returns SDM_DEFERRED instead of running its finishing pass: the caller's next
                              kernel finishes them (sdm_gn_apply_fused folds the finishing pass into the GroupNorm that
@@ -156,6 +170,7 @@ typedef struct sdm_igemm_desc {
                              the library does not split K the call behaves as usual and returns SDM_OK. */
 } sdm_igemm_desc;
 
+#define SDM_ACT_EXP 3       /* sdm_igemm_bf16 with col_shift only */
 #define SDM_DEFERRED 1
 #define SDM_STATS_DONE 2
 int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream);
@@ -278,6 +293,13 @@ int sdm_attn_scores_small(const void* qkv, int64_t ld, int batch, int S, int hea
                           int bf16, sdm_stream_t s);
 int sdm_attn_pv_small(const void* P, int64_t ldp, const void* qkv, int64_t ld, int batch, int S, int heads, int dk, void* res,
                       int64_t ldr, int bf16, sdm_stream_t s);
+
+/* Folds the per-M-tile column statistics of sdm_igemm_bf16(col_stats) [batch][ntiles][N][2] into the vectors pass 2 takes:
+ * neg_max[b][j] = -max_t m, inv_sum[b][j] = 1 / sum_t l_t exp(m_t - max). */
+int sdm_attn_colstats_combine(const float* col_stats, int batch, int ntiles, int N, float* neg_max, float* inv_sum,
+                              sdm_stream_t s);
+/* M-tile height sdm_igemm_bf16 will use for this problem (the ntiles of col_stats = ceil(M / that)). */
+int sdm_igemm_bf16_tile_m(const sdm_igemm_desc* d);
 
 /* Sinusoidal timestep features (custom_layers.py:84-90): out[n][D] = [sin(t f_i) | cos(t f_i)]. t is int64;
  * freq[D/2] is the frequency table exp(-i ln(1e4)/(D/2-1)), computed once on the host exactly as the reference does. */

@@ -111,14 +111,21 @@ __global__ __launch_bounds__(64 * AS_WAVES) void attn_scores_small_kernel(const 
   }
   __syncthreads();
 
-  // column softmax over the queries: 32 threads per key
+  // column softmax over the queries: 32 threads per key.  The scaled score is ROUNDED (stored back) before the maximum is
+  // subtracted: hipcc contracts x * scale - m into fma(x, scale, -m) (also through __fmul_rn), and then the maximum
+  // element itself comes out as the rounding error of x*scale -- ~1e-7 of the score, i.e. exp(+1e9) = inf once logits
+  // reach 1e16 (an untrained net under guidance does that) -- where softmax(scores * scale) of the reference gives exp(0)
   const int key = tid >> 5, sub = tid & 31;
   float m = -INFINITY;
-  for (int i = sub; i < S; i += 32) m = fmaxf(m, xs[i][key] * scale);
+  for (int i = sub; i < S; i += 32) {
+    const float v = xs[i][key] * scale;
+    xs[i][key] = v;
+    m = fmaxf(m, v);
+  }
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   float l = 0.f;
-  for (int i = sub; i < S; i += 32) l += __expf(xs[i][key] * scale - m);
+  for (int i = sub; i < S; i += 32) l += __expf(xs[i][key] - m);
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
   if (sub == 0) {
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(64 * AS_WAVES) void attn_scores_small_kernel(const 
   for (int e = tid; e < S * AS_KB; e += 64 * AS_WAVES) {
     const int i = e >> 4, jj = e & 15;
     const int j = j0 + jj;
-    if (j < S) store1<T>(pb + (long long)i * ldp + j, __expf(xs[i][jj] * scale - s_m[jj]) * s_inv[jj]);
+    if (j < S) store1<T>(pb + (long long)i * ldp + j, __expf(xs[i][jj] - s_m[jj]) * s_inv[jj]);
     else if (j < ldp) store1<T>(pb + (long long)i * ldp + j, 0.f);      // reduction padding of P.V stays zero
   }
 }

@@ -279,6 +279,59 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
   const bf16_t* res16 = (const bf16_t*)d.res;
   const bf16_t* res216 = (const bf16_t*)d.res2;
   const bf16_t* dz16 = (const bf16_t*)d.dact_z;
+  if (d.col_stats) {
+    // pass 1 of the two-pass column softmax: {max, sum exp} over this tile's rows for each of its columns; nothing else
+    // is stored.  A lane holds ONE column of each of its TN 32x32 blocks (rows: 16 registers x TM blocks, the other half
+    // of the rows on lane ^ 32), the WM waves of a tile column meet in LDS.
+    __syncthreads();                         // the ring is free
+    float* red = smem;                       // [WM][BN][2]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float v = acc[i][j][r] * d.alpha;
+          asm volatile("" : "+v"(v));        // rounded product: never contracted into the subtraction below
+          v = s_orow[row] >= 0 ? v : -INFINITY;
+          acc[i][j][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sm = 0.f;
+      if (mx > -INFINITY) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sm += __expf(acc[i][j][r] - mx);
+      }
+      sm += __shfl_xor(sm, 32, 64);
+      if (h == 0) {
+        const int cl = wn * TN * 32 + j * 32 + l31;
+        red[(wm * BN + cl) * 2] = mx;
+        red[(wm * BN + cl) * 2 + 1] = sm;
+      }
+    }
+    __syncthreads();
+    for (int cl = tid; cl < BN; cl += NT) {
+      const int col = n0 + cl;
+      if (col >= N) continue;
+      float mx = red[cl * 2], sm = red[cl * 2 + 1];
+#pragma unroll
+      for (int w = 1; w < WM; ++w) {
+        const float m2 = red[(w * BN + cl) * 2], s2 = red[(w * BN + cl) * 2 + 1];
+        const float mn = fmaxf(mx, m2);
+        sm = (mx > -INFINITY ? sm * __expf(mx - mn) : 0.f) + (m2 > -INFINITY ? s2 * __expf(m2 - mn) : 0.f);
+        mx = mn;
+      }
+      float* o = d.col_stats + (long long)blockIdx.z * d.col_stats_bs + ((long long)tile_m * N + col) * 2;
+      o[0] = mx;
+      o[1] = sm;
+    }
+    return;
+  }
   if (L.splitk == 1 && L.vec_epi) {
     // Staged through LDS: the accumulator layout gives a lane ONE column and 16 scattered rows of a 32x32 tile, i.e.
     // 2-byte stores; the ring (no longer needed) is reused as an fp32 [BM][BN] tile so that every lane finishes 4
@@ -294,6 +347,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
     // a thread keeps its column quad over all its rows (NT % C4 == 0): the bias is loaded once, not per row
     const int mycol = n0 + (tid % C4) * 4;
     const f32x4 bias4 = (d.bias && mycol < N) ? *(const f32x4*)(d.bias + mycol) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // pass 2 of the two-pass column softmax: per-(batch entry, column) shift before and factor after the activation
+    const f32x4 cshift4 = (d.col_shift && mycol < N) ? *(const f32x4*)(d.col_shift + (long long)blockIdx.z * d.colvec_bs + mycol)
+                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 cmul4 = (d.col_mul && mycol < N) ? *(const f32x4*)(d.col_mul + (long long)blockIdx.z * d.colvec_bs + mycol)
+                                                 : f32x4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
     for (int sl = 0; sl < SL; ++sl) {
       __syncthreads();                       // every wave is done with the last K-step's fragments / the previous slab
@@ -315,16 +373,27 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
         const long long orow = s_orow[row];
         if (orow < 0 || col >= N) continue;
         f32x4 v = *(const f32x4*)(Ct + prow * BN + c4);
+        if (d.col_shift) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] * d.alpha + bias4[q];
+          for (int q = 0; q < 4; ++q) {
+            float t = v[q] * d.alpha;
+            asm volatile("" : "+v"(t));      // the rounded product pass 1 took its maxima from (no fma contraction)
+            v[q] = __expf(t + cshift4[q]) * cmul4[q];
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = v[q] * d.alpha + bias4[q];
+        }
         if (pre16) {     // pre-activation copy for the backward (training)
           u16x4 zo;
 #pragma unroll
           for (int q = 0; q < 4; ++q) zo[q] = f2bf(v[q]);
           *(u16x4*)(pre16 + obo + orow * d.ldo + col) = zo;
         }
+        if (!d.col_shift) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = sdm_act(v[q], d.act);
+          for (int q = 0; q < 4; ++q) v[q] = sdm_act(v[q], d.act);
+        }
         if (res16) {
           const u16x4 rv = *(const u16x4*)(res16 + rbo + orow * d.ldres + col);
 #pragma unroll
@@ -712,7 +781,7 @@ static int bf_validate(const sdm_igemm_desc* d, int out_f32) {
   SDM_CHECK_ARG(d != nullptr, "igemm_bf16: null desc");
   SDM_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "igemm_bf16: bad M/N/K %d %d %d", d->M, d->N, d->K);
   SDM_CHECK_ARG(d->batch >= 1 && d->bdiv >= 1, "igemm_bf16: bad batch");
-  SDM_CHECK_ARG(d->a.p0 && d->b && d->out, "igemm_bf16: null operand");
+  SDM_CHECK_ARG(d->a.p0 && d->b && (d->out || d->col_stats), "igemm_bf16: null operand");
   SDM_CHECK_ARG(d->Ht > 0 && d->Wt > 0 && d->M % (d->Ht * d->Wt) == 0, "igemm_bf16: M %d not a multiple of Ht*Wt", d->M);
   SDM_CHECK_ARG(d->nphase >= 1 && d->nphase <= SDM_MAX_PHASE, "igemm_bf16: nphase");
   for (int p = 0; p < d->nphase; ++p) SDM_CHECK_ARG(d->ntaps[p] >= 1 && d->ntaps[p] <= SDM_MAX_TAPS, "igemm_bf16: ntaps");
@@ -727,7 +796,14 @@ static int bf_validate(const sdm_igemm_desc* d, int out_f32) {
   SDM_CHECK_ARG(d->a.scale == nullptr, "igemm_bf16: no affine-on-load on bf16 rows (materialise it: sdm_affine_residual_bf16)");
   SDM_CHECK_ARG(!(out_f32 && (d->res || d->res2 || d->out_preact)), "igemm_bf16: fp32 output takes no residual / pre-activation copy");
   SDM_CHECK_ARG(d->ostride >= 1 && d->sstride >= 1 && d->Ho > 0 && d->Wo > 0, "igemm_bf16: bad strides/output dims");
-  SDM_CHECK_ARG(d->act >= 0 && d->act <= 2, "igemm_bf16: bad act");
+  SDM_CHECK_ARG((d->act >= 0 && d->act <= 2) || (d->act == SDM_ACT_EXP && d->col_shift), "igemm_bf16: bad act");
+  SDM_CHECK_ARG((d->col_shift == nullptr) == (d->col_mul == nullptr), "igemm_bf16: col_shift and col_mul come together");
+  SDM_CHECK_ARG(d->col_shift == nullptr || (d->act == SDM_ACT_EXP && !d->bias && !d->res && !d->res2 && !d->out_preact &&
+                                            !d->dact_z && aligned16(d->col_shift) && aligned16(d->col_mul) && d->colvec_bs % 4 == 0),
+                "igemm_bf16: the column shift / factor epilogue is exp(alpha*acc + shift) * factor alone (16-byte aligned vectors)");
+  SDM_CHECK_ARG(d->col_stats == nullptr || (!d->col_shift && !d->bias && !d->res && !d->res2 && !d->out_preact && !d->dact_z &&
+                                            !d->defer_epilogue && d->nphase == 1),
+                "igemm_bf16: column statistics take alpha only");
   SDM_CHECK_ARG(!d->defer_epilogue || (d->batch == 1 && !d->res && !d->res2 && !d->out_preact && !d->dact_z && !out_f32),
                 "igemm_bf16: a deferred epilogue carries only alpha / bias / activation (batch 1, bf16 output)");
   return SDM_OK;
@@ -774,9 +850,11 @@ static void bf_plan(const sdm_igemm_desc* d, bool big_ok, int* cfg, int* splitk,
   // sizes where these GEMMs are tiny the sampling step is launch-bound and the extra finishing launch costs more than
   // the shorter K walk saves (measured: 837 -> 801 steps/s at batch 4) -- left to the force override
   if (d->batch > 1) sk = 1;
+  if (d->col_stats || d->col_shift) sk = 1;      // the column epilogues see whole sums
   if (force) {
     int fc = 0, fs = 1;
     if (sscanf(force, "%d,%d", &fc, &fs) == 2 && fc >= 0 && fc <= 3 && (fc < 2 || big_ok)) { c = fc; sk = fc >= 2 ? 1 : (fs < 1 ? 1 : (fs > T ? T : fs)); }
+    if (d->col_stats || d->col_shift) sk = 1;
   }
   *cfg = c;
   *splitk = sk;
@@ -865,6 +943,42 @@ extern "C" size_t sdm_igemm_bf16_workspace_bytes(const sdm_igemm_desc* d) {
   return need;
 }
 
+extern "C" int sdm_igemm_bf16_tile_m(const sdm_igemm_desc* d) {
+  if (bf_validate(d, 0) != SDM_OK) return -1;
+  static const char* nofast = getenv("SDM_BF16_FAST");
+  const bool fast = d->K % BKE == 0 && (d->a.p1 == nullptr || d->a.csplit % BKE == 0) && !(nofast && nofast[0] == '0');
+  int cfg, sk;
+  size_t need;
+  // the large tiles need the vector epilogue; pass 1 stores no tile and pass 2's caller guarantees it (N % 4 == 0, aligned
+  // rows), so both passes of a column softmax plan the same tiles
+  bf_plan(d, fast && d->N % 4 == 0, &cfg, &sk, &need);
+  return kBfCfgs[cfg].bm;
+}
+
+__global__ __launch_bounds__(256) void colstats_combine_kernel(const float* __restrict__ st, int ntiles, int N,
+                                                               float* __restrict__ neg_max, float* __restrict__ inv_sum) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  const float* p = st + (long long)blockIdx.y * ntiles * N * 2;
+  float mx = -INFINITY;
+  for (int t = 0; t < ntiles; ++t) mx = fmaxf(mx, p[((long long)t * N + j) * 2]);
+  float sm = 0.f;
+  for (int t = 0; t < ntiles; ++t) {
+    const float m = p[((long long)t * N + j) * 2], l = p[((long long)t * N + j) * 2 + 1];
+    if (m > -INFINITY) sm += l * __expf(m - mx);
+  }
+  neg_max[(long long)blockIdx.y * N + j] = -mx;
+  inv_sum[(long long)blockIdx.y * N + j] = 1.f / sm;
+}
+extern "C" int sdm_attn_colstats_combine(const float* col_stats, int batch, int ntiles, int N, float* neg_max, float* inv_sum,
+                                         sdm_stream_t s) {
+  SDM_CHECK_ARG(col_stats && neg_max && inv_sum && batch > 0 && ntiles > 0 && N > 0, "attn_colstats_combine: bad args");
+  hipLaunchKernelGGL(colstats_combine_kernel, dim3(cdiv(N, 256), batch), dim3(256), 0, (hipStream_t)s, col_stats, ntiles, N,
+                     neg_max, inv_sum);
+  SDM_CHECK_LAUNCH("attn_colstats_combine");
+  return SDM_OK;
+}
+
 extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t stream) {
   int rc = bf_validate(d, out_f32);
   if (rc != SDM_OK) return rc;
@@ -878,7 +992,8 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
     const size_t esz = out_f32 ? 4 : 2;
     auto al = [](const void* q, size_t a) { return (((uintptr_t)q) & (a - 1)) == 0; };
     static const char* noepi = getenv("SDM_BF16_VEC_EPI");
-    L.vec_epi = d->N % 4 == 0 && al(d->out, 4 * esz) && d->ldo % 4 == 0 && d->o_bs0 % 4 == 0 && d->o_bs1 % 4 == 0 &&
+    L.vec_epi = d->col_stats ? d->N % 4 == 0 :
+                d->N % 4 == 0 && al(d->out, 4 * esz) && d->ldo % 4 == 0 && d->o_bs0 % 4 == 0 && d->o_bs1 % 4 == 0 &&
                 (d->bias == nullptr || al(d->bias, 16)) &&
                 (d->res == nullptr || (al(d->res, 8) && d->ldres % 4 == 0 && d->r_bs0 % 4 == 0 && d->r_bs1 % 4 == 0)) &&
                 (d->res2 == nullptr || (al(d->res2, 8) && d->ldres2 % 4 == 0)) &&
@@ -892,6 +1007,8 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
   size_t need;
   bf_plan(d, fast && L.vec_epi, &cfg, &L.splitk, &need);
   if (L.splitk > 1 && (d->ws == nullptr || d->ws_bytes < need)) L.splitk = 1;
+  if (d->col_shift && !L.vec_epi)
+    return sdm_set_error(SDM_ERR_ARG, "igemm_bf16: the column shift / factor epilogue needs N %% 4 == 0 and aligned output rows");
   const int bm = kBfCfgs[cfg].bm, bn = kBfCfgs[cfg].bn;
   const int ntm = cdiv(d->M, bm);
   L.ntn = cdiv(d->N, bn);

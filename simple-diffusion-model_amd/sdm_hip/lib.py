@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDM_HIP_LIB") or os.path.join(_HERE, "libsdm_hip.so")     # override: kernel experiments only
 
 MAX_PHASE, MAX_TAPS = 4, 16
-ACT_NONE, ACT_SILU, ACT_TANH = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_TANH, ACT_EXP = 0, 1, 2, 3
 
 fp = C.c_void_p  # device pointers travel as integers
 
@@ -38,7 +38,9 @@ class IgemmDesc(C.Structure):
         ("res", fp), ("ldres", C.c_int64), ("r_bs0", C.c_int64), ("r_bs1", C.c_int64),
         ("res2", fp), ("ldres2", C.c_int64),
         ("dact_z", fp), ("ldz", C.c_int64), ("dact_ncols", C.c_int),
-        ("ws", fp), ("ws_bytes", C.c_size_t), ("gn_sums", fp), ("defer_epilogue", C.c_int),
+        ("ws", fp), ("ws_bytes", C.c_size_t), ("gn_sums", fp),
+        ("col_stats", fp), ("col_stats_bs", C.c_int64), ("col_shift", fp), ("col_mul", fp), ("colvec_bs", C.c_int64),
+        ("defer_epilogue", C.c_int),
     ]
 
 
@@ -130,6 +132,8 @@ _PROTOS = {
     # bf16 storage path (forward / sampling)
     "sdm_igemm_bf16": (_i, [C.POINTER(IgemmDesc), _i, fp]),
     "sdm_igemm_bf16_workspace_bytes": (_sz, [C.POINTER(IgemmDesc)]),
+    "sdm_igemm_bf16_tile_m": (_i, [C.POINTER(IgemmDesc)]),
+    "sdm_attn_colstats_combine": (_i, [fp, _i, _i, _i, fp, fp, fp]),
     "sdm_cast_bf16": (_i, [fp, fp, _sz, fp]),
     "sdm_stem_conv_bf16": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
     "sdm_head_conv_bf16": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),

@@ -499,6 +499,7 @@ def _pad4(s):
     return (s + 3) // 4 * 4
 
 
+TWO_PASS_ATTN = [os.environ.get("SDM_ATTN_TWOPASS", "1") != "0"]   # bf16 rows, S > 256: no S x S fp32 scores in HBM
 SMALL_ATTN = [os.environ.get("SDM_SMALL_ATTN", "1") != "0"]     # short sequences: the two-launch core of sdm_attn.hip
 SMALL_ATTN_MAX_S = 256
 
@@ -570,22 +571,51 @@ def attention_core_fwd_bf16(qkv, n, S, heads, dk, keep_p=False):
     if _small_attn_ok(qkv, S, dk):
         res, P = attention_core_small(qkv, n, S, heads, dk, Sp)
         return (res, P) if keep_p else res
-    scores = torch.empty((n * heads, S, Sp), dtype=torch.float32, device=dev)
-    d = _base_desc(S, S, dk)
-    d.batch, d.bdiv = n * heads, heads
-    d.Ht, d.Wt = S, 1
-    plain_rows(d.a, qkv, rows=S)
-    d.a_bs0, d.a_bs1 = S * ld, 3 * dk
-    d.b, d.ldb, d.b_kmajor = qkv.data_ptr() + 2 * dk, ld, 0
-    d.b_bs0, d.b_bs1 = S * ld, 3 * dk
-    d.ntaps[0] = 1
-    d.Ho, d.Wo = S, 1
-    d.out, d.ldo, d.o_bs0, d.o_bs1 = _p(scores), Sp, heads * S * Sp, S * Sp
-    d.alpha = float(dk) ** -0.5
-    _launch_igemm(d, dev, bf16=True, out_f32=True)
-    P = torch.empty((n * heads, S, Sp), dtype=BF16, device=dev)
-    lib.call("sdm_col_softmax_bf16", _p(scores), _p(P), n * heads, S, Sp, Sp, _stream())
-    del scores
+    B = n * heads
+
+    def scores_desc():
+        d = _base_desc(S, S, dk)
+        d.batch, d.bdiv = B, heads
+        d.Ht, d.Wt = S, 1
+        plain_rows(d.a, qkv, rows=S)
+        d.a_bs0, d.a_bs1 = S * ld, 3 * dk
+        d.b, d.ldb, d.b_kmajor = qkv.data_ptr() + 2 * dk, ld, 0
+        d.b_bs0, d.b_bs1 = S * ld, 3 * dk
+        d.ntaps[0] = 1
+        d.Ho, d.Wo = S, 1
+        d.alpha = float(dk) ** -0.5
+        return d
+
+    P = torch.empty((B, S, Sp), dtype=BF16, device=dev)
+    if TWO_PASS_ATTN[0] and S % 8 == 0:
+        # Two passes of the SAME scores GEMM instead of an S x S fp32 round trip through HBM (custom_layers.py:144-150; the
+        # softmax runs down the columns -- over the queries -- so its statistics belong to the key):
+        #   pass 1: per M-tile column statistics {max, sum exp} from the accumulators, nothing stored; folded per key;
+        #   pass 2: the epilogue writes exp(s - m_j) / l_j once, as the bf16 probabilities P.V (and the backward) read.
+        d = scores_desc()
+        d.out, d.ldo = _p(P), Sp                 # (any output: the query only plans the tiles)
+        tile_m = lib.raw("sdm_igemm_bf16_tile_m")(C.byref(d))
+        if tile_m <= 0:
+            raise lib.SdmError("attention (two-pass): " + lib.last_error())
+        nt = (S + tile_m - 1) // tile_m
+        stats = torch.empty((B, nt, S, 2), dtype=torch.float32, device=dev)
+        d.col_stats, d.col_stats_bs = _p(stats), nt * S * 2
+        d.out, d.ldo = None, 0
+        _launch_igemm(d, dev, bf16=True)
+        neg_max = torch.empty((B, S), dtype=torch.float32, device=dev)
+        inv_sum = torch.empty((B, S), dtype=torch.float32, device=dev)
+        lib.call("sdm_attn_colstats_combine", _p(stats), B, nt, S, _p(neg_max), _p(inv_sum), _stream())
+        d = scores_desc()
+        d.out, d.ldo, d.o_bs0, d.o_bs1 = _p(P), Sp, heads * S * Sp, S * Sp
+        d.act, d.col_shift, d.col_mul, d.colvec_bs = lib.ACT_EXP, _p(neg_max), _p(inv_sum), S
+        _launch_igemm(d, dev, bf16=True)
+    else:
+        scores = torch.empty((B, S, Sp), dtype=torch.float32, device=dev)
+        d = scores_desc()
+        d.out, d.ldo, d.o_bs0, d.o_bs1 = _p(scores), Sp, heads * S * Sp, S * Sp
+        _launch_igemm(d, dev, bf16=True, out_f32=True)
+        lib.call("sdm_col_softmax_bf16", _p(scores), _p(P), B, S, Sp, Sp, _stream())
+        del scores
     Vt = torch.empty((n * heads, dk, Sp), dtype=BF16, device=dev)
     lib.call("sdm_transpose_bf16", qkv.data_ptr() + 4 * dk, ld, S * ld, 3 * dk, heads, _p(Vt), Sp, dk * Sp, n * heads, S, dk,
              _stream())

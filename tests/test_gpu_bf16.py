@@ -347,3 +347,38 @@ def test_row_patch_kernel_forced():
                         "forward_bf16_vs_golden or grads_bf16_vs_reference_golden or fused_tail or standard_architecture"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("n,S,heads,dk", [(2, 1024, 1, 512), (1, 512, 2, 64), (1, 4096, 1, 128), (3, 264, 1, 64)])
+def test_two_pass_column_softmax_attention(dev, n, S, heads, dk):
+    """bf16 attention core for S > 256 without the S x S fp32 scores in HBM (custom_layers.py:144-150): pass 1 of the scores
+    GEMM leaves per-M-tile column statistics, pass 2 writes exp(s - m_j) / l_j as bf16.  Against a float64 computation on
+    the same bf16 rows, against the materialised-scores path it replaces, for one / several heads, tile-ragged S, and for
+    logits of 1e13 (rounded products must be identical in both passes: no fma contraction)."""
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(S + dk)
+    qkv = torch.randn(n * S, heads * 3 * dk, generator=g)
+    v = qkv.view(n, S, heads, 3, dk)
+    gain = 6.0 / dk ** 0.25
+    v[:, :, :, 0] *= gain
+    v[:, :, :, 1] *= gain
+    x = qkv.to(dev).to(torch.bfloat16)
+    xr = x.double().view(n, S, heads, 3, dk).cpu()
+    q, k, vv = xr[:, :, :, 0], xr[:, :, :, 1], xr[:, :, :, 2]
+    attn = (torch.einsum("nihd,njhd->nijh", q, k) * dk ** -0.5).softmax(dim=1)
+    want = torch.einsum("nijh,njhd->nihd", attn, vv).reshape(n * S, heads * dk)
+    assert ops.TWO_PASS_ATTN[0] and not ops._small_attn_ok(x, S, dk)
+    res, P = ops.attention_core_fwd_bf16(x, n, S, heads, dk, keep_p=True)
+    Pw = attn.permute(0, 3, 1, 2).reshape(n * heads, S, S)
+    assert rel(P[:, :, :S].float(), Pw) < 6e-3, rel(P[:, :, :S].float(), Pw)
+    assert rel(res.float(), want) < 8e-3, rel(res.float(), want)
+    ops.TWO_PASS_ATTN[0] = False
+    try:
+        res2, P2 = ops.attention_core_fwd_bf16(x, n, S, heads, dk, keep_p=True)
+    finally:
+        ops.TWO_PASS_ATTN[0] = True
+    assert P2.shape == P.shape and rel(P.float(), P2.float()) < 6e-3 and rel(res.float(), res2.float()) < 8e-3
+    big = (torch.randn(n * S, heads * 3 * dk, generator=g) * 3e6).to(dev).to(torch.bfloat16)
+    r1, P1 = ops.attention_core_fwd_bf16(big, n, S, heads, dk, keep_p=True)
+    assert bool(torch.isfinite(r1.float()).all()) and bool(torch.isfinite(P1.float()).all())
+    assert float((P1[:, :, :S].float().sum(1) - 1).abs().max()) < 2e-2

@@ -1064,3 +1064,11 @@ def test_short_sequence_attention_core(dev, n, S, heads, dk, bf16):
         ops.SMALL_ATTN[0] = True
     assert rel(res.float(), res2.float()) < (1.5e-2 if bf16 else 2e-5)
     assert P2.shape == P.shape and P2.dtype == P.dtype
+    if not bf16:
+        # logits of 1e13..1e17 (an untrained net under classifier-free guidance reaches them): the scaled score must be
+        # rounded before the column maximum is subtracted, or the maximum itself becomes exp(rounding error) = inf
+        for mag in (1e6, 1e8):
+            big = (torch.randn(n * S, heads * 3 * dk, generator=g) * mag).to(dev)
+            r1, P1 = ops.attention_core_small(big, n, S, heads, dk, Sp)
+            assert bool(torch.isfinite(r1).all()) and bool(torch.isfinite(P1[:, :, :S]).all())
+            assert float((P1[:, :, :S].sum(1) - 1).abs().max()) < 1e-5
