@@ -204,6 +204,30 @@ def other_configs(dev, sched, net64):
     del net, xT
     torch.cuda.empty_cache()
 
+    # ---- C5 sampling: the SR cold-diffusion sampler at 256x256 (generate_sr_images_diffusion.py:141-238,
+    # diffusion_sampling_algorithms.py:150-217): 6-channel input (x_t | noised low-res condition), Tanh head, N=8, hipGraph
+    torch.manual_seed(0)
+    net = U_Net(**dict(STANDARD, in_channel=6, image_recon=True)).to(dev).eval()
+    n = 8
+    xT = torch.randn(n, 3, 256, 256, device=dev, generator=g)
+    cond = torch.randn(n, 3, 256, 256, device=dev, generator=g)
+    for dt, b, peak in ((torch.bfloat16, 2, PEAK_BF16_MFMA_TFLOPS), (torch.float32, 4, PEAK_FP32_MFMA_TFLOPS)):
+        net.set_inference_dtype(dt)
+        S.cold_diffusion_sampling(net, sched, xT, xT, 1, 1000, cond, None, 500, dev, quiet)          # warm (3 U-Net calls)
+        torch.cuda.synchronize()
+        nsteps = 51 if b == 2 else 11
+        t0 = time.perf_counter()
+        S.cold_diffusion_sampling(net, sched, xT, xT, 1, 1000, cond, None, 20 if b == 2 else 100, dev, quiet)   # incl. capture
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / nsteps
+        rec = fractions(ms, FWD_FLOPS_PER_IMAGE[256] * n, alg_bytes(n, 256, b, False, 3_456), peak)
+        rec.update(dtype="bf16" if b == 2 else "f32", batch=n, images_per_s=n * 1e3 / ms,
+                   what="SR cold-diffusion sampling step at 256x256 (U-Net forward on cat(x_t, condition) + fused update), "
+                        "hipGraph, %d steps incl. capture" % nsteps)
+        out["c5_sr_sample_256" + ("_bf16" if b == 2 else "")] = rec
+    del net, xT, cond
+    torch.cuda.empty_cache()
+
     # ---- C4 / C5 per-GPU training steps (fp32; and the bf16 training path when the trainer offers it)
     def train_ms(cfg, res, n, sr, dtype):
         torch.manual_seed(0)
@@ -396,6 +420,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     launches_per_step = (lib.launch_count() - l0) / args.steps
+    # what the shipped CLI loop pays: one float(loss) read-back per step (train_diffusion.py:354,366 read it twice), so the
+    # host cannot run ahead of the GPU
+    barrier()
+    tl0 = time.perf_counter()
+    for _ in range(max(1, args.steps // 2)):
+        float(tr.step(x0))
+    barrier()
+    step_with_loss_ms = 1e3 * (time.perf_counter() - tl0) / max(1, args.steps // 2)
     # roofline leg: the same step, eager, with a HIP event pair around every contraction launch on its launch stream
     # (a replayed hipGraph cannot carry per-kernel events, so this is a second, shorter region of the same workload);
     # weight-gradient kernels normally overlap data-gradient kernels on a second stream: for the per-kernel numbers that
@@ -471,6 +503,7 @@ def main():
         "loss": loss_v,
         "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
         "launches_per_step": launches_per_step,
+        "step_with_loss_ms": step_with_loss_ms,
         "train_step_hipgraph": bool(graphed),
         "step_tflops_algorithmic": step_flops / (dt / args.steps) / 1e12,
         "step_flop_frac": step_flops / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,

@@ -50,7 +50,7 @@ __device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float v) {
 
 #define AS_KB 16          // keys per workgroup
 #define AS_MAXS 256       // queries held on chip
-#define AS_WAVES 8
+#define AS_WAVES 16         // 1024 threads: one 16-query tile per wave at S = 256, four waves per SIMD to hide load latency
 
 // v_mfma_f32_16x16x4_f32: lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; D: col = l&15, row = 4*(l>>4) + reg.
 // Each lane loads 4 consecutive reduction elements (16 bytes of fp32, 8 of bf16) at k0 + 4*(l>>4) and feeds element s to
@@ -86,23 +86,47 @@ __global__ __launch_bounds__(64 * AS_WAVES) void attn_scores_small_kernel(const 
       const int q = min(t * 16 + li, S - 1);
       const T* qp = qb + (long long)q * ld + kbeg + 4 * kg;
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-      int k = 0;
-      for (; k + 64 <= kper; k += 64) {        // four 16-deep steps per trip: eight loads in flight ahead of 16 MFMAs
-        f32x4_t a[4], bb[4];
+      // 64 reduction elements per trip (eight 16-byte loads -> 16 MFMAs); the loads of trip k+1 are issued before the
+      // MFMAs of trip k (two register sets), so a wave waits for memory once, not once per trip
+      f32x4_t a[2][4], bb[2][4];
+      const int trips = kper >> 6;
+      if (trips > 0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          a[u] = load4<T>(qp + k + 16 * u);
-          bb[u] = load4<T>(kp + k + 16 * u);
+          a[0][u] = load4<T>(qp + 16 * u);
+          bb[0][u] = load4<T>(kp + 16 * u);
+        }
+      }
+      for (int tr = 0; tr < trips; tr += 2) {
+        if (tr + 1 < trips) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            a[1][u] = load4<T>(qp + (tr + 1) * 64 + 16 * u);
+            bb[1][u] = load4<T>(kp + (tr + 1) * 64 + 16 * u);
+          }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], bb[u][s], acc, 0, 0, 0);
-      }
-      for (; k < kper; k += 16) {
-        const f32x4_t a = load4<T>(qp + k), bb = load4<T>(kp + k);
+          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][u][s], bb[0][u][s], acc, 0, 0, 0);
+        if (tr + 1 < trips) {
+          if (tr + 2 < trips) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bb[s], acc, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+              a[0][u] = load4<T>(qp + (tr + 2) * 64 + 16 * u);
+              bb[0][u] = load4<T>(kp + (tr + 2) * 64 + 16 * u);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][u][s], bb[1][u][s], acc, 0, 0, 0);
+        }
+      }
+      for (int k = trips << 6; k < kper; k += 16) {
+        const f32x4_t a1 = load4<T>(qp + k), b1 = load4<T>(kp + k);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b1[s], acc, 0, 0, 0);
       }
       // D: column (key) = li, rows (queries) = 4*kg + r
 #pragma unroll
@@ -111,23 +135,24 @@ __global__ __launch_bounds__(64 * AS_WAVES) void attn_scores_small_kernel(const 
   }
   __syncthreads();
 
-  // column softmax over the queries: 32 threads per key.  The scaled score is ROUNDED (stored back) before the maximum is
+  // column softmax over the queries: TPK threads per key.  The scaled score is ROUNDED (stored back) before the maximum is
   // subtracted: hipcc contracts x * scale - m into fma(x, scale, -m) (also through __fmul_rn), and then the maximum
   // element itself comes out as the rounding error of x*scale -- ~1e-7 of the score, i.e. exp(+1e9) = inf once logits
   // reach 1e16 (an untrained net under guidance does that) -- where softmax(scores * scale) of the reference gives exp(0)
-  const int key = tid >> 5, sub = tid & 31;
+  constexpr int TPK = 64 * AS_WAVES / AS_KB;          // threads per key (a power of two <= 64: one wave or a part of one)
+  const int key = tid / TPK, sub = tid % TPK;
   float m = -INFINITY;
-  for (int i = sub; i < S; i += 32) {
+  for (int i = sub; i < S; i += TPK) {
     const float v = xs[i][key] * scale;
     xs[i][key] = v;
     m = fmaxf(m, v);
   }
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  for (int o = TPK / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   float l = 0.f;
-  for (int i = sub; i < S; i += 32) l += __expf(xs[i][key] - m);
+  for (int i = sub; i < S; i += TPK) l += __expf(xs[i][key] - m);
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+  for (int o = TPK / 2; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
   if (sub == 0) {
     s_m[key] = m;
     s_inv[key] = 1.f / l;

@@ -23,7 +23,16 @@ struct BfLaunch {
   int vec_epi;   // 4-column vector epilogue allowed (N % 4 == 0, 8-byte aligned output / residual rows, 16-byte bias)
   int gn_stats;  // accumulate per-(image, channel) sum / sum of squares of the stored outputs into d.gn_sums
   long long out_rows;   // output rows of ONE batch entry (split-K scratch is [batch][out_rows][N])
+  int pow2, lw, lhw;    // prologue shortcuts, as in sdm_igemm.hip: Wt == 1 << lw, Ht * Wt == 1 << lhw
+  int plain_out;        // output row == tile-grid row
 };
+
+static inline int ilog2_exact_bf(long v) {
+  if (v <= 0 || (v & (v - 1)) != 0) return -1;
+  int l = 0;
+  while ((1L << l) < v) ++l;
+  return l;
+}
 
 __device__ float g_zero_chunk_bf[4];
 
@@ -81,10 +90,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
     const int m = m0 + r;
     long long o = -1;
     if (m < d.M) {
-      const int n = m / HtWt, rem = m - n * HtWt;
-      const int y = rem / d.Wt, x = rem - y * d.Wt;
-      const int oy = y * d.ostride + d.ph_oy[phase], ox = x * d.ostride + d.ph_ox[phase];
-      if (oy < d.Ho && ox < d.Wo) o = ((long long)n * d.Ho + oy) * d.Wo + ox;
+      if (L.plain_out) {
+        o = m;
+      } else {
+        int n, y, x;
+        if (L.pow2) { n = m >> L.lhw; const int rem = m & (HtWt - 1); y = rem >> L.lw; x = rem & (d.Wt - 1); }
+        else { n = m / HtWt; const int rem = m - n * HtWt; y = rem / d.Wt; x = rem - y * d.Wt; }
+        const int oy = y * d.ostride + d.ph_oy[phase], ox = x * d.ostride + d.ph_ox[phase];
+        if (oy < d.Ho && ox < d.Wo) o = ((long long)n * d.Ho + oy) * d.Wo + ox;
+      }
     }
     s_orow[r] = o;
   }
@@ -99,8 +113,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
   for (int i = 0; i < AIT; ++i) {
     const int m = m0 + arow + RA * i;
     if (m < d.M) {
-      const int n = m / HtWt, rem = m - n * HtWt;
-      const int y = rem / d.Wt, x = rem - y * d.Wt;
+      int n, y, x;
+      if (L.pow2) { n = m >> L.lhw; const int rem = m & (HtWt - 1); y = rem >> L.lw; x = rem & (d.Wt - 1); }
+      else { n = m / HtWt; const int rem = m - n * HtWt; y = rem / d.Wt; x = rem - y * d.Wt; }
       a_ys[i] = y * d.sstride;
       a_xs[i] = x * d.sstride;
       a_base[i] = ((long long)n * d.a.H + a_ys[i]) * d.a.W + a_xs[i];
@@ -454,6 +469,22 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
     return;
   }
   if constexpr (BM > 128) return;     // the large tiles are only planned with the vector epilogue and without split-K
+  if (L.splitk > 1) {                 // partial sums: nothing but the atomics
+    float* wsb = d.ws + (long long)blockIdx.z * L.out_rows * N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + l31;
+        if (col >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long orow = s_orow[wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+          if (orow >= 0) atomicAdd(wsb + orow * N + col, acc[i][j][r]);
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -760,10 +791,10 @@ __global__ __launch_bounds__(256) void splitk_epilogue_bf16_kernel(const sdm_ige
   const bf16_t* res16 = (const bf16_t*)d.res;
   const bf16_t* res216 = (const bf16_t*)d.res2;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const long long grow = e / d.N;
+    const long long grow = sdm_idiv(e, d.N);
     const int col = (int)(e - grow * d.N);
-    const long long b = grow / rows, orow = grow - b * rows;
-    const long long b0 = b / d.bdiv, b1 = b - b0 * d.bdiv;
+    const long long b = sdm_idiv(grow, rows), orow = grow - b * rows;
+    const long long b0 = sdm_idiv(b, d.bdiv), b1 = b - b0 * d.bdiv;
     const long long oo = b0 * d.o_bs0 + b1 * d.o_bs1 + orow * d.ldo + col;
     float v = d.ws[e] * d.alpha + (d.bias ? d.bias[col] : 0.f);
     d.ws[e] = 0.f;
@@ -841,10 +872,20 @@ static void bf_plan(const sdm_igemm_desc* d, bool big_ok, int* cfg, int* splitk,
     if (cost256 < cost128 && !(nobig && nobig[0] == '0')) c = 2;
   }
   if (c == 1 && t64 < 512) {
-    sk = (int)((512 + t64 - 1) / t64);
-    if (sk > T / 4) sk = T / 4;
-    if (sk > 64) sk = 64;
-    if (sk < 1) sk = 1;
+    // Split K only where it pays for its finishing launch.  A 64-deep K-step of a 64x64 tile is ~0.3 us (operand fetch
+    // bound), the finishing pass (a dependent launch reading atomically summed fp32) ~5 us of a sampling step's chain
+    // (profiles/r03_sample_n1_bf16_kernel_stats.csv: 37 finishing launches at 4.9 us were 20 % of the N=1 step, most of them
+    // behind K walks of 8-18 steps that a single workgroup finishes sooner than that).
+    static const char* ts_s = getenv("SDM_BF16_TSTEP");
+    static const char* te_s = getenv("SDM_BF16_SPLIT_COST");
+    const double ts = ts_s ? atof(ts_s) : 0.30, tepi = te_s ? atof(te_s) : 5.0;
+    int cap = T / 4;
+    if (cap > 64) cap = 64;
+    double best = (double)cdiv(t64, 512) * T * ts;
+    for (int k2 = 2; k2 <= cap; ++k2) {
+      const double t = (double)cdiv(t64 * k2, 512) * ((double)T / k2) * ts + tepi;
+      if (t < best) { best = t; sk = k2; }
+    }
   }
   // batched problems (attention cores): the scratch is indexed per batch entry, so splitting works, but at the batch
   // sizes where these GEMMs are tiny the sampling step is launch-bound and the extra finishing launch costs more than
@@ -988,6 +1029,10 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
   L.out_f32 = out_f32 ? 1 : 0;
   L.kchunks = cdiv(d->K, BKE);
   L.out_rows = (long long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
+  L.lw = ilog2_exact_bf(d->Wt);
+  L.lhw = ilog2_exact_bf((long)d->Ht * d->Wt);
+  L.pow2 = L.lw >= 0 && L.lhw >= 0;
+  L.plain_out = d->nphase == 1 && d->ostride == 1 && d->Ho == d->Ht && d->Wo == d->Wt && d->ph_oy[0] == 0 && d->ph_ox[0] == 0;
   {
     const size_t esz = out_f32 ? 4 : 2;
     auto al = [](const void* q, size_t a) { return (((uintptr_t)q) & (a - 1)) == 0; };
@@ -1232,7 +1277,7 @@ __global__ __launch_bounds__(1024) void gn_affine_bf16_kernel(const bf16_t* __re
       for (int u = 0; u < 8; ++u) {
         const long long e = e0 + (long long)u * 1024;
         if (e < tot4) {
-          const long long pix = e / q4;
+          const long long pix = sdm_idiv(e, q4);
           const int c = (int)(e - pix * q4) * 4;
           const u16x4 v = *(const u16x4*)(base + pix * ldy + c);
           const float a = bf2f(v.x), b = bf2f(v.y), cc = bf2f(v.z), dd = bf2f(v.w);
@@ -1245,7 +1290,7 @@ __global__ __launch_bounds__(1024) void gn_affine_bf16_kernel(const bf16_t* __re
     }
   } else {
     for (long long e = threadIdx.x; e < total; e += 1024) {
-      const long long pix = e / cpg;
+      const long long pix = sdm_idiv(e, cpg);
       const int c = (int)(e - pix * cpg);
       const double v = bf2f(base[pix * ldy + c]);
       s1 += v;
@@ -1302,9 +1347,9 @@ __global__ __launch_bounds__(256) void affine_residual_bf16_kernel(const bf16_t*
   const int C8 = C >> 3;
   const long long total = rows * C8;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const long long r = e / C8;
+    const long long r = sdm_idiv(e, C8);
     const int c = (int)(e - r * C8) * 8;
-    const int n = (int)(r / HW);
+    const int n = (int)sdm_idiv(r, HW);
     const u16x8 v = *(const u16x8*)(y + r * ldy + c);
     float f[8];
 #pragma unroll
@@ -1466,7 +1511,7 @@ extern "C" int sdm_transpose_bf16(const uint16_t* src, int64_t ld_src, int64_t s
 __global__ __launch_bounds__(256) void rows_to_nchw_kernel(const float* __restrict__ rows, long long ld, float* __restrict__ out,
                                                            int C, long long HW, long long P) {
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long long)gridDim.x * 256) {
-    const long long n = p / HW, rem = p - n * HW;
+    const long long n = sdm_idiv(p, HW), rem = p - n * HW;
     for (int c = 0; c < C; ++c) out[(n * C + c) * HW + rem] = rows[p * ld + c];
   }
 }
@@ -1523,7 +1568,7 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_bf16_kernel(void* __restr
     for (int u = 0; u < 8; ++u) {
       const long long e = e0 + (long long)u * 1024;
       if (e < tot4) {
-        const long long pix = e / q4;
+        const long long pix = sdm_idiv(e, q4);
         const int c = (int)(e - pix * q4) * 4;
         const f32x4 b = (raw && bias) ? *(const f32x4*)(bias + g * cpg + c) : zero4;
         const f32x4 v = gnf16_value(src, base + pix * lds_ + c, raw, alpha, b, act);
@@ -1553,7 +1598,7 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_bf16_kernel(void* __restr
   __syncthreads();
   const float mu = s_stat[0], rstd = s_stat[1];
   for (long long e = threadIdx.x; e < tot4; e += 1024) {
-    const long long pix = e / q4;
+    const long long pix = sdm_idiv(e, q4);
     const int c = (int)(e - pix * q4) * 4;
     const int ch = g * cpg + c;
     const long long si = base + pix * lds_ + c;

@@ -786,9 +786,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_bf16_kernel(const bf16_t* __
   const int C8 = C >> 3;
   const long long total = rows * C8;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const long long r = e / C8;
+    const long long r = sdm_idiv(e, C8);
     const int c = (int)(e - r * C8) * 8;
-    const int n = (int)(r / HW);
+    const int n = (int)sdm_idiv(r, HW);
     const float* k = coef + (long long)n * 3 * C + c;
     const u16x8 dv = *(const u16x8*)(dout + r * lddo + c);
     const u16x8 yv = *(const u16x8*)(y + r * ldy + c);
@@ -966,7 +966,7 @@ extern "C" int sdm_colsum_bf16(const uint16_t* x, int64_t ldx, int rows, int C, 
 __global__ __launch_bounds__(256) void nchw_to_rows_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int C,
                                                                 int Cp, long long HW, long long P) {
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long long)gridDim.x * 256) {
-    const long long n = p / HW, rem = p - n * HW;
+    const long long n = sdm_idiv(p, HW), rem = p - n * HW;
     for (int c0 = 0; c0 < Cp; c0 += 8) {
       u16x8 o;
 #pragma unroll

@@ -22,7 +22,26 @@ struct IgemmLaunch {
   int splitk, ntn, kchunks;
   int mfast;   // tile order inside one XCD's run: 0 = N-tiles fastest (A rows shared in L2), 1 = M-tiles fastest (B shared)
   long long out_rows;   // output rows of ONE batch entry (split-K scratch is [batch][out_rows][N])
+  // prologue shortcuts (host-derived, wave-uniform): every feature map of the U-Net has power-of-two sides, and most
+  // launches write their rows in tile order -- the general per-row divisions cost ~350 instructions of a ~1800-instruction
+  // prologue, a measurable part of the ~7 us a launch of a few K-steps takes (tools/scratch/tiny_igemm.py)
+  int pow2, lw, lhw;    // Wt == 1 << lw and Ht * Wt == 1 << lhw
+  int plain_out;        // output row == tile-grid row (one phase, unit output stride, Ho x Wo == Ht x Wt)
 };
+
+static inline int ilog2_exact(long v) {   // log2 of a power of two, else -1
+  if (v <= 0 || (v & (v - 1)) != 0) return -1;
+  int l = 0;
+  while ((1L << l) < v) ++l;
+  return l;
+}
+static inline void igemm_geometry(IgemmLaunch& L) {
+  const sdm_igemm_desc& d = L.d;
+  L.lw = ilog2_exact(d.Wt);
+  L.lhw = ilog2_exact((long)d.Ht * d.Wt);
+  L.pow2 = L.lw >= 0 && L.lhw >= 0;
+  L.plain_out = d.nphase == 1 && d.ostride == 1 && d.Ho == d.Ht && d.Wo == d.Wt && d.ph_oy[0] == 0 && d.ph_ox[0] == 0;
+}
 
 // Workgroups go to the 8 XCDs round-robin by linear id and every XCD has its own L2.  Remap blockIdx.x so that one
 // XCD owns a contiguous run of the tile order: tiles that share an operand then meet in one L2 instead of each
@@ -401,10 +420,15 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
     int m = m0 + r;
     long long o = -1;
     if (m < d.M) {
-      int n = m / HtWt, rem = m - n * HtWt;
-      int y = rem / d.Wt, x = rem - y * d.Wt;
-      int oy = y * d.ostride + d.ph_oy[phase], ox = x * d.ostride + d.ph_ox[phase];
-      if (oy < d.Ho && ox < d.Wo) o = ((long long)n * d.Ho + oy) * d.Wo + ox;
+      if (L.plain_out) {
+        o = m;
+      } else {
+        int n, y, x;
+        if (L.pow2) { n = m >> L.lhw; const int rem = m & (HtWt - 1); y = rem >> L.lw; x = rem & (d.Wt - 1); }
+        else { n = m / HtWt; const int rem = m - n * HtWt; y = rem / d.Wt; x = rem - y * d.Wt; }
+        int oy = y * d.ostride + d.ph_oy[phase], ox = x * d.ostride + d.ph_ox[phase];
+        if (oy < d.Ho && ox < d.Wo) o = ((long long)n * d.Ho + oy) * d.Wo + ox;
+      }
     }
     s_orow[r] = o;
   }
@@ -420,8 +444,9 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
   for (int i = 0; i < AIT; ++i) {
     int m = m0 + arow + RA * i;
     if (m < d.M) {
-      int n = m / HtWt, rem = m - n * HtWt;
-      int y = rem / d.Wt, x = rem - y * d.Wt;
+      int n, y, x;
+      if (L.pow2) { n = m >> L.lhw; const int rem = m & (HtWt - 1); y = rem >> L.lw; x = rem & (d.Wt - 1); }
+      else { n = m / HtWt; const int rem = m - n * HtWt; y = rem / d.Wt; x = rem - y * d.Wt; }
       a_ys[i] = y * d.sstride;
       a_xs[i] = x * d.sstride;
       a_base[i] = ((long long)n * d.a.H + a_ys[i]) * d.a.W + a_xs[i];
@@ -568,6 +593,22 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
   }
 
   // ---- epilogue (same contract as igemm_kernel)
+  if (L.splitk > 1) {       // partial sums: nothing but the atomics
+    float* wsb = d.ws + (long long)blockIdx.z * L.out_rows * N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + l31;
+        if (col >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long orow = s_orow[wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+          if (orow >= 0) atomicAdd(wsb + orow * N + col, acc[i][j][r]);
+        }
+      }
+    return;
+  }
   const long long obo = b0 * d.o_bs0 + b1 * d.o_bs1;
   const long long rbo = b0 * d.r_bs0 + b1 * d.r_bs1;
 #pragma unroll
@@ -630,10 +671,10 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const sdm_igemm_de
     const int N4 = d.N >> 2;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < all_rows * N4; e += (long long)gridDim.x * 256) {
-      const long long grow = e / N4;
+      const long long grow = sdm_idiv(e, N4);
       const int col = (int)(e - grow * N4) * 4;
-      const long long b = grow / rows, orow = grow - b * rows;
-      const long long b0 = b / d.bdiv, b1 = b - b0 * d.bdiv;
+      const long long b = sdm_idiv(grow, rows), orow = grow - b * rows;
+      const long long b0 = sdm_idiv(b, d.bdiv), b1 = b - b0 * d.bdiv;
       const long long oo = b0 * d.o_bs0 + b1 * d.o_bs1 + orow * d.ldo + col;
       f32x4* w = (f32x4*)(d.ws + grow * d.N + col);
       f32x4 v = *w * d.alpha;
@@ -655,10 +696,10 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const sdm_igemm_de
   }
   const long long total = all_rows * d.N;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const long long grow = e / d.N;
+    const long long grow = sdm_idiv(e, d.N);
     const int col = (int)(e - grow * d.N);
-    const long long b = grow / rows, orow = grow - b * rows;
-    const long long b0 = b / d.bdiv, b1 = b - b0 * d.bdiv;
+    const long long b = sdm_idiv(grow, rows), orow = grow - b * rows;
+    const long long b0 = sdm_idiv(b, d.bdiv), b1 = b - b0 * d.bdiv;
     const long long oo = b0 * d.o_bs0 + b1 * d.o_bs1 + orow * d.ldo + col;
     float v = d.ws[e] * d.alpha + (d.bias ? d.bias[col] : 0.f);
     d.ws[e] = 0.f;  // leave the scratch zero-filled for the next split-K launch
@@ -964,6 +1005,8 @@ static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* w
   static const int kOcc[4] = {2, 4, 3, 2};
   static const char* pen_s = getenv("SDM_IGEMM_BIGTILE_PENALTY");   // tuning aid: extra cycles charged to 128-row tiles
   const double pen = pen_s ? atof(pen_s) : 0.0;
+  static const char* sc_s = getenv("SDM_IGEMM_SPLIT_COST");    // cycles charged to a split (finishing launch + atomic drain)
+  const double split_cost = sc_s ? atof(sc_s) : 6000.0;
   double best = 1e300;
   int bc = 1, bs = 1;
   for (int c = 0; c < 4; ++c) {
@@ -978,7 +1021,7 @@ static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* w
       const long per_cu = (nb + 255) / 256;
       const double overlap = (per_cu >= 2 && kOcc[c] >= 2) ? 0.92 : 1.0;
       double t = (double)per_cu * ((double)T / sk) * (kMfma[c] + kOvh[c] + ((c == 0 || c == 3) ? pen : 0.0)) * overlap + 3000.0;
-      if (sk > 1) t += 6000.0 + (double)out_rows * d->batch * N * 4.0 * sk / 256.0 / 4.0;   // atomics + finishing launch
+      if (sk > 1) t += split_cost + (double)out_rows * d->batch * N * 4.0 * sk / 256.0 / 4.0;   // atomics + finishing launch
       if (t < best) { best = t; bc = c; bs = sk; }
     }
   }
@@ -1068,6 +1111,7 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
   const bool vec = vecA && vecB && d->K % 4 == 0 && (!d->b_kmajor || d->N % 4 == 0);
   const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;
   L.out_rows = out_rows;
+  igemm_geometry(L);
   const int tcfg = cfg == 4 ? 1 : cfg;              // (the streaming kernel has no tile table entry)
   const int ntm = cdiv(d->M, kCfgs[tcfg].bm);
   L.ntn = cdiv(d->N, kCfgs[tcfg].bn);

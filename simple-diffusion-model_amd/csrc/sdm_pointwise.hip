@@ -385,7 +385,7 @@ __global__ __launch_bounds__(1024) void gn_affine_kernel(const float* __restrict
       for (int u = 0; u < 8; ++u) {
         const long long e = e0 + (long long)u * 1024;
         if (e < tot4) {
-          const long long pix = e / q4;
+          const long long pix = sdm_idiv(e, q4);
           const int c = (int)(e - pix * q4) * 4;
           const f32x4 v = *(const f32x4*)(base + pix * ldy + c);
           p1 += (v.x + v.y) + (v.z + v.w);
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(1024) void gn_affine_kernel(const float* __restrict
     }
   } else {
     for (long long e = threadIdx.x; e < total; e += 1024) {
-      const long long pix = e / cpg;
+      const long long pix = sdm_idiv(e, cpg);
       const int c = (int)(e - pix * cpg);
       const double v = base[pix * ldy + c];
       s1 += v;
@@ -458,9 +458,9 @@ __global__ __launch_bounds__(256) void affine_residual_kernel(const float* __res
     const int C4 = C >> 2;
     const long long total = rows * C4;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-      const long long r = e / C4;
+      const long long r = sdm_idiv(e, C4);
       const int c = (int)(e - r * C4) * 4;
-      const int n = (int)(r / HW);
+      const int n = (int)sdm_idiv(r, HW);
       f32x4 v = *(const f32x4*)(y + r * ldy + c);
       if (scale) {
         const f32x4 a = *(const f32x4*)(scale + (long long)n * ans + c);
@@ -473,9 +473,9 @@ __global__ __launch_bounds__(256) void affine_residual_kernel(const float* __res
   } else {
     const long long total = rows * C;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-      const long long r = e / C;
+      const long long r = sdm_idiv(e, C);
       const int c = (int)(e - r * C);
-      const int n = (int)(r / HW);
+      const int n = (int)sdm_idiv(r, HW);
       float v = y[r * ldy + c];
       if (scale) v = v * scale[(long long)n * ans + c] + shift[(long long)n * ans + c];
       if (x0) v += (c < csplit) ? x0[r * ldx0 + c] : x1[r * ldx1 + (c - csplit)];
@@ -622,9 +622,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     const int C4 = C >> 2;
     const long long total = rows * C4;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-      const long long r = e / C4;
+      const long long r = sdm_idiv(e, C4);
       const int c = (int)(e - r * C4) * 4;
-      const int n = (int)(r / HW);
+      const int n = (int)sdm_idiv(r, HW);
       const float* k = coef + (long long)n * 3 * C + c;
       const f32x4 k0 = *(const f32x4*)k, k1 = *(const f32x4*)(k + C), k2 = *(const f32x4*)(k + 2 * C);
       f32x4 v = k0 * *(const f32x4*)(dout + r * lddo + c) + k1 * *(const f32x4*)(y + r * ldy + c) + k2;
@@ -639,9 +639,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   }
   const long long total = rows * C;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const long long r = e / C;
+    const long long r = sdm_idiv(e, C);
     const int c = (int)(e - r * C);
-    const int n = (int)(r / HW);
+    const int n = (int)sdm_idiv(r, HW);
     const float* k = coef + (long long)n * 3 * C + c;
     float v = k[0] * dout[r * lddo + c] + k[C] * y[r * ldy + c] + k[2 * C];
     if (z) v *= sdm_dsilu(z[r * ldz + c]);
@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(256) void u8_gather_nchw_kernel(const uint8_t* __re
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const long long b = e / (HW * C);
     long long r = e - b * HW * C;
-    const int c = (int)(r / HW);
+    const int c = (int)sdm_idiv(r, HW);
     r -= (long long)c * HW;
     const int y = (int)(r / W), x = (int)(r - (long long)y * W);
     const int xs = (flip && flip[b]) ? W - 1 - x : x;
@@ -1371,7 +1371,7 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_kernel(float* __restrict_
     for (int u = 0; u < 8; ++u) {
       const long long e = e0 + (long long)u * 1024;
       if (e < tot4) {
-        const long long pix = e / q4;
+        const long long pix = sdm_idiv(e, q4);
         const int c = (int)(e - pix * q4) * 4;
         const f32x4 b = (raw && bias) ? *(const f32x4*)(bias + g * cpg + c) : zero4;
         const f32x4 v = gnf_value(base + pix * lds_ + c, raw, alpha, b, act);
@@ -1405,7 +1405,7 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_kernel(float* __restrict_
   __syncthreads();
   const float mu = s_stat[0], rstd = s_stat[1];
   for (long long e = threadIdx.x; e < tot4; e += 1024) {
-    const long long pix = e / q4;
+    const long long pix = sdm_idiv(e, q4);
     const int c = (int)(e - pix * q4) * 4;
     const int ch = g * cpg + c;
     float* sp = base + pix * lds_ + c;

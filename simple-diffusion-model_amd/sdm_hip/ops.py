@@ -500,6 +500,9 @@ def _pad4(s):
 
 
 TWO_PASS_ATTN = [os.environ.get("SDM_ATTN_TWOPASS", "1") != "0"]   # bf16 rows, S > 256: no S x S fp32 scores in HBM
+TWO_PASS_MAX_DK = 512    # measured (tools/attn_probe.py): at head width 512 the second scores GEMM costs less than the fp32
+                         # round trip + softmax pass it replaces (8 x 4096 tokens: 823 -> 697 us; 128 x 1024: 923 -> 854;
+                         # 32 x 1024: 228 -> 214); at 1024 it costs more (16 x 1024: 166 -> 181 us)
 SMALL_ATTN = [os.environ.get("SDM_SMALL_ATTN", "1") != "0"]     # short sequences: the two-launch core of sdm_attn.hip
 SMALL_ATTN_MAX_S = 256
 
@@ -587,7 +590,7 @@ def attention_core_fwd_bf16(qkv, n, S, heads, dk, keep_p=False):
         return d
 
     P = torch.empty((B, S, Sp), dtype=BF16, device=dev)
-    if TWO_PASS_ATTN[0] and S % 8 == 0:
+    if TWO_PASS_ATTN[0] and S % 8 == 0 and dk <= TWO_PASS_MAX_DK:
         # Two passes of the SAME scores GEMM instead of an S x S fp32 round trip through HBM (custom_layers.py:144-150; the
         # softmax runs down the columns -- over the queries -- so its statistics belong to the key):
         #   pass 1: per M-tile column statistics {max, sum exp} from the accumulators, nothing stored; folded per key;

@@ -1015,11 +1015,13 @@ def test_ddpm_sampling_is_seedable_and_noise_is_fresh_per_step(dev, O):
         torch.manual_seed(seed)
         return S.ddpm_sampling(net, sch, xT, 1, hi, None, lab, "cuda", quiet, use_graph=graph)
     a, b, c, d = run(11, True), run(11, True), run(11, False), run(12, True)
-    assert torch.equal(a, b) and torch.equal(a, c) and not torch.allclose(a, d)
+    # (not bit-equal: split-K sums are fp32 atomics, whose order varies from launch to launch)
+    assert torch.allclose(a, b, rtol=1e-3, atol=1e-4) and torch.allclose(a, c, rtol=1e-3, atol=1e-4)
+    assert float((a - d).abs().mean()) > 1e-2
     # injected zeros == what the in-kernel path would give with sigma = 0: the difference is the noise the kernel added
     z0 = torch.zeros(8, 2, 3, 16, 16)
     det = S.ddpm_sampling(net, sch, xT, 1, 8, None, lab, "cuda", quiet, noise=z0, use_graph=True)
-    assert float((a - det).abs().mean()) > 1e-3
+    assert float((a - det).abs().mean()) > 1e-2
 
 
 @pytest.mark.parametrize("n,S,heads,dk", [(1, 16, 1, 1024), (2, 64, 1, 512), (1, 256, 1, 512), (3, 35, 2, 16), (2, 100, 3, 48),
