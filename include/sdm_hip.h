@@ -171,6 +171,7 @@ typedef struct sdm_igemm_desc {
 } sdm_igemm_desc;
 
 #define SDM_ACT_EXP 3       /* sdm_igemm_bf16 with col_shift only */
+#define SDM_NOT_APPLICABLE 3  /* sdm_gn_apply_coop: shape outside its envelope, nothing launched */
 #define SDM_DEFERRED 1
 #define SDM_STATS_DONE 2
 int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream);
@@ -247,6 +248,20 @@ int sdm_gn_apply_fused(const float* src, int64_t ld_src, int src_raw, float alph
                        int images, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
                        const float* mod, int mod_nstride, const float* x0, int64_t ldx0, const float* x1, int64_t ldx1,
                        int csplit, float* out, int64_t ldo, sdm_stream_t s);
+/* sdm_gn_apply_fused for the layers where one workgroup per (image, group) is the wrong shape (a group = 16-32 bytes of
+ * every 512-byte row at 64x64 / 32x32): a workgroup owns a SLAB of whole rows (coalesced, one sweep, values kept in
+ * registers) and the slabs of an image exchange the per-group sums once through fp64 atomics and an arrival counter
+ * (agent-scope atomics on both sides; placement-independent; at most 256 workgroups, all resident).  fp32 (bf16 = 0) or
+ * bf16 rows / residual / output; src_raw as in sdm_gn_apply_fused(_bf16).  `state`: sdm_gn_apply_coop_state_bytes() of
+ * device memory, ZERO on first use, owned by ONE stream at a time; every launch leaves it zero.  Returns
+ * SDM_NOT_APPLICABLE (nothing launched) when the shape is outside the envelope -- fewer than two slabs, more than 256
+ * workgroups, channel counts that are not powers of two: the caller then runs sdm_gn_apply_fused. */
+size_t sdm_gn_apply_coop_state_bytes(void);
+int sdm_gn_apply_coop(const void* src, int64_t ld_src, int src_raw, float alpha, const float* bias, int act, int images, int HW,
+                      int C, int groups, float eps, const float* gamma, const float* beta, const float* mod, int mod_nstride,
+                      const void* x0, int64_t ldx0, const void* x1, int64_t ldx1, int csplit, void* out, int64_t ldo, int bf16,
+                      void* state, size_t state_bytes, sdm_stream_t s);
+
 /* The same pass inside a TRAINING step (small layers, where the step is a chain of dependent launches): additionally
  * leaves what the block's backward reads -- mean / rstd [images][groups] (both or neither) and, for raw sums, the conv's own
  * finished rows y_out (activated, pitch ldy) and z_out (pre-activation, optional; same pitch).  sdm_igemm(defer_epilogue)

@@ -1,0 +1,236 @@
+// Fused conv-block tail (see gn_apply_fused_kernel in sdm_pointwise.hip) for the layers where ONE workgroup per (image,
+// group) is the wrong shape: at 64x64 / 32x32 a GroupNorm group is 4-8 channels of 1024-4096 pixel rows, i.e. 16-32 bytes
+// out of every 512-byte row, read twice by 32 workgroups (profiles/r03_sample_n1_kernel_stats.csv: 23-33 us per launch
+// at N=1, a sixth of the whole denoise step together).
+//
+// Here a workgroup owns a SLAB of whole rows (coalesced 16-byte accesses, all channels), keeps its elements in registers
+// (one sweep over memory instead of two), and the slabs of an image meet ONCE to exchange the per-group sums:
+//   partial sums (fp32 in the lane, fp64 from the wave on) -> LDS -> fp64 atomic adds into sums[image][group][2]
+//   -> every adding lane drains its atomics (s_waitcnt vmcnt(0)) -> workgroup barrier -> one lane bumps arrive[image]
+//   -> one lane polls arrive[image] (agent-scope relaxed loads, s_sleep) until every slab of the image has arrived
+//   -> the sums are read back with agent-scope atomic loads (8-byte atomics on both sides: no cache holds them)
+//   -> apply from registers, store; the last slab to DEPART zeroes the sums and both counters for the next launch.
+// Placement-independent: nothing depends on which CU / XCD a slab runs on.  Residency: the grid is at most 256 workgroups
+// of 1024 threads (the host refuses anything larger, and falls back to the one-workgroup-per-group kernel), i.e. at most
+// half of what the chip holds, and an image's slabs are consecutive block ids; a poll therefore always ends -- at worst
+// after kernels of other streams have drained.
+#include <stdlib.h>
+
+#include "sdm_common.h"
+
+#define GC_T 1024
+#define GC_MAXV 4          // float4 / bf16x4 elements a lane keeps
+#define GC_MAXG 64         // groups
+
+struct GnCoopArgs {
+  const void* src; long long ld_src; int raw; float alpha; const float* bias; int act;
+  int HW, C, groups; float eps;
+  const float* gamma; const float* beta; const float* mod; int mod_ns;
+  const void* x0; long long ldx0; const void* x1; long long ldx1; int csplit;
+  void* out; long long ldo;
+  int slab_rows, lc4, lq4;       // rows per slab; log2(C/4); log2(channel quads per group)
+  double* sums;                  // [images][GC_MAXG][2], zero between launches
+  unsigned* ctr;                 // [images][2] arrive / depart, zero between launches
+};
+
+template <bool BF>
+__global__ __launch_bounds__(GC_T) void gn_apply_coop_kernel(const GnCoopArgs a) {
+  __shared__ double ls[2][GC_MAXG];
+  __shared__ float st[2][GC_MAXG];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int n = blockIdx.y, nsl = gridDim.x;
+  const int C4 = a.C >> 2, q4 = 1 << a.lq4;
+  const int r0 = blockIdx.x * a.slab_rows;
+  const int nrows = min(a.slab_rows, a.HW - r0);
+  const long long row0 = (long long)n * a.HW + r0;
+  const int quad = tid & (C4 - 1);             // the same for every element of this lane (1024 % C4 == 0)
+  const int c = quad * 4, g = quad >> a.lq4;
+  const int rstep = GC_T >> a.lc4;             // rows between two elements of a lane
+  const int rfirst = tid >> a.lc4;
+  if (tid < 2 * GC_MAXG) (&ls[0][0])[tid] = 0.0;
+  __syncthreads();
+
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 b4 = (a.raw && a.bias) ? *(const f32x4*)(a.bias + c) : zero4;
+  f32x4 v[GC_MAXV];
+  float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < GC_MAXV; ++k) {
+    const int r = rfirst + k * rstep;
+    v[k] = zero4;
+    if (r < nrows) {
+      const long long idx = (row0 + r) * a.ld_src + c;
+      if (a.raw) {
+        f32x4 t = *(const f32x4*)((const float*)a.src + idx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          t[i] = sdm_act(t[i] * a.alpha + b4[i], a.act);
+          if (BF) t[i] = bf2f(f2bf(t[i]));           // statistics of the values the next layer sees
+        }
+        v[k] = t;
+        *(f32x4*)((float*)a.src + idx) = zero4;        // the split-K scratch goes back zero-filled
+      } else if (BF) {
+        const u16x4 u = *(const u16x4*)((const bf16_t*)a.src + idx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[k][i] = bf2f(u[i]);
+      } else {
+        v[k] = *(const f32x4*)((const float*)a.src + idx);
+      }
+      p1 += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+      p2 += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+    }
+  }
+  // lanes of one wave that share a group: the q4 neighbouring quads, and (C4 < 64) the lanes C4 apart
+  for (int o = 1; o < q4; o <<= 1) {
+    p1 += __shfl_xor(p1, o, 64);
+    p2 += __shfl_xor(p2, o, 64);
+  }
+  for (int o = C4; o < 64; o <<= 1) {
+    p1 += __shfl_xor(p1, o, 64);
+    p2 += __shfl_xor(p2, o, 64);
+  }
+  if ((lane & (q4 - 1)) == 0 && (C4 >= 64 || lane < C4)) {
+    atomicAdd(&ls[0][g], (double)p1);
+    atomicAdd(&ls[1][g], (double)p2);
+  }
+  __syncthreads();
+  double* gs = a.sums + (long long)n * GC_MAXG * 2;
+  unsigned* ctr = a.ctr + n * 2;
+  if (tid < a.groups) {
+    atomicAdd(gs + tid * 2, ls[0][tid]);
+    atomicAdd(gs + tid * 2 + 1, ls[1][tid]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this lane's adds are performed before the arrival below
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nsl) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+  if (tid < a.groups) {
+    const double s1 = __hip_atomic_load(gs + tid * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double s2 = __hip_atomic_load(gs + tid * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double total = (double)a.HW * (a.C / a.groups);
+    const double mean = s1 / total;
+    double var = s2 / total - mean * mean;
+    if (var < 0.0) var = 0.0;
+    st[0][tid] = (float)mean;
+    st[1][tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  __syncthreads();
+  const float mu = st[0][g], rstd = st[1][g];
+  const f32x4 ga = *(const f32x4*)(a.gamma + c), be = *(const f32x4*)(a.beta + c);
+  f32x4 sc, sh;
+  if (a.mod) {
+    const f32x4 sm = *(const f32x4*)(a.mod + (long long)n * a.mod_ns + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {       // the two-step form of sdm_gn_affine + sdm_affine_residual: scale*v + shift
+      sc[i] = rstd * ga[i] * sm[i];
+      sh[i] = (be[i] - mu * rstd * ga[i]) * sm[i] + sm[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sc[i] = rstd * ga[i];
+      sh[i] = be[i] - mu * rstd * ga[i];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < GC_MAXV; ++k) {
+    const int r = rfirst + k * rstep;
+    if (r >= nrows) continue;
+    const long long row = row0 + r;
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = v[k][i] * sc[i] + sh[i];
+    if (a.x0) {
+      if (BF) {
+        const u16x4 u = (c < a.csplit) ? *(const u16x4*)((const bf16_t*)a.x0 + row * a.ldx0 + c)
+                                       : *(const u16x4*)((const bf16_t*)a.x1 + row * a.ldx1 + (c - a.csplit));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] += bf2f(u[i]);
+      } else {
+        o += (c < a.csplit) ? *(const f32x4*)((const float*)a.x0 + row * a.ldx0 + c)
+                            : *(const f32x4*)((const float*)a.x1 + row * a.ldx1 + (c - a.csplit));
+      }
+    }
+    if (BF) {
+      u16x4 u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) u[i] = f2bf(o[i]);
+      *(u16x4*)((bf16_t*)a.out + row * a.ldo + c) = u;
+    } else {
+      *(f32x4*)((float*)a.out + row * a.ldo + c) = o;
+    }
+  }
+  // departure: the last slab of the image leaves the exchange state zero for the next launch (every slab has read the sums:
+  // it departs after its reads)
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (unsigned)nsl - 1) {
+      for (int i = 0; i < a.groups * 2; ++i) __hip_atomic_store(gs + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+static int ilog2x(long v) {
+  if (v <= 0 || (v & (v - 1)) != 0) return -1;
+  int l = 0;
+  while ((1L << l) < v) ++l;
+  return l;
+}
+
+#define GC_MAX_IMAGES 256
+extern "C" size_t sdm_gn_apply_coop_state_bytes(void) {
+  return (size_t)GC_MAX_IMAGES * GC_MAXG * 2 * sizeof(double) + (size_t)GC_MAX_IMAGES * 2 * sizeof(unsigned);
+}
+
+extern "C" int sdm_gn_apply_coop(const void* src, int64_t ld_src, int src_raw, float alpha, const float* bias, int act, int images,
+                                 int HW, int C, int groups, float eps, const float* gamma, const float* beta, const float* mod,
+                                 int mod_nstride, const void* x0, int64_t ldx0, const void* x1, int64_t ldx1, int csplit, void* out,
+                                 int64_t ldo, int bf16, void* state, size_t state_bytes, sdm_stream_t s) {
+  SDM_CHECK_ARG(src && gamma && beta && out && images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_apply_coop: bad args");
+  SDM_CHECK_ARG(state && state_bytes >= sdm_gn_apply_coop_state_bytes() && aligned16(state), "gn_apply_coop: state buffer");
+  SDM_CHECK_ARG(x0 == nullptr || x1 != nullptr || csplit >= C, "gn_apply_coop: csplit < C without second source");
+  SDM_CHECK_ARG(act >= 0 && act <= 2, "gn_apply_coop: bad act");
+  const int cpg = C / groups;
+  const int lc4 = ilog2x(C / 4), lq4 = cpg % 4 == 0 ? ilog2x(cpg / 4) : -1;
+  // applicability (else the caller runs the one-workgroup-per-group kernel): power-of-two quads per row and per group, a
+  // row no wider than the workgroup, at least two slabs per image and at most 256 workgroups in all
+  if (C % 4 != 0 || lc4 < 0 || lq4 < 0 || (C / 4) > GC_T || groups > GC_MAXG || images > GC_MAX_IMAGES) return SDM_NOT_APPLICABLE;
+  const long long quads = (long long)HW * (C / 4);
+  long long nsl = 1;
+  while (nsl * GC_T * GC_MAXV < quads) nsl <<= 1;
+  // The exchange costs ~8 us whatever the size (fp64 atomics, the arrival poll and the read-back are each a round trip
+  // to the memory side: measured 10-14 us per launch from 2048 to 131072 quads against 6-33 us for the per-group kernel),
+  // so it is used from 32 slabs per image on -- the 64x64 maps -- and declined below (SDM_GN_COOP_MIN_SLABS overrides).
+  static const char* ms = getenv("SDM_GN_COOP_MIN_SLABS");
+  const long long min_slabs = ms ? atoll(ms) : 32;
+  if (nsl < 2 || nsl < min_slabs || nsl * images > 256) return SDM_NOT_APPLICABLE;
+  const int slab_rows = (int)((HW + nsl - 1) / nsl);
+  if ((long long)slab_rows * (C / 4) > (long long)GC_T * GC_MAXV) return SDM_NOT_APPLICABLE;
+  const size_t esz = bf16 ? 2 : 4;
+  auto al = [](const void* q, size_t a_) { return (((uintptr_t)q) & (a_ - 1)) == 0; };
+  SDM_CHECK_ARG(al(src, src_raw ? 16 : 4 * esz) && ld_src % 4 == 0 && al(out, 4 * esz) && ldo % 4 == 0 && aligned16(gamma) &&
+                    aligned16(beta) && (mod == nullptr || (aligned16(mod) && mod_nstride % 4 == 0)) &&
+                    (bias == nullptr || aligned16(bias)) && (x0 == nullptr || (al(x0, 4 * esz) && ldx0 % 4 == 0 && csplit % 4 == 0)) &&
+                    (x1 == nullptr || (al(x1, 4 * esz) && ldx1 % 4 == 0)),
+                "gn_apply_coop: rows and tables must be aligned to four elements");
+  GnCoopArgs a;
+  a.src = src; a.ld_src = ld_src; a.raw = src_raw; a.alpha = alpha; a.bias = bias; a.act = act;
+  a.HW = HW; a.C = C; a.groups = groups; a.eps = eps;
+  a.gamma = gamma; a.beta = beta; a.mod = mod; a.mod_ns = mod_nstride;
+  a.x0 = x0; a.ldx0 = ldx0; a.x1 = x1; a.ldx1 = ldx1; a.csplit = x1 ? csplit : (1 << 30);
+  a.out = out; a.ldo = ldo;
+  a.slab_rows = slab_rows; a.lc4 = lc4; a.lq4 = lq4;
+  a.sums = (double*)state;
+  a.ctr = (unsigned*)((char*)state + (size_t)GC_MAX_IMAGES * GC_MAXG * 2 * sizeof(double));
+  dim3 grid((unsigned)nsl, images);
+  if (bf16) hipLaunchKernelGGL(gn_apply_coop_kernel<true>, grid, dim3(GC_T), 0, (hipStream_t)s, a);
+  else hipLaunchKernelGGL(gn_apply_coop_kernel<false>, grid, dim3(GC_T), 0, (hipStream_t)s, a);
+  SDM_CHECK_LAUNCH("gn_apply_coop");
+  return SDM_OK;
+}

