@@ -306,6 +306,13 @@ int sdm_col_softmax_bwd(const float* p, float* dp, int batch, int S, int64_t lds
  *   sdm_attn_pv_small: res[i][head*dk + c] = sum_j P[b][i][j] v_j[c]   (V read k-major: no transpose copy). */
 int sdm_attn_scores_small(const void* qkv, int64_t ld, int batch, int S, int heads, int dk, float scale, void* P, int64_t ldp,
                           int bf16, sdm_stream_t s);
+/* The same core when nothing but the result is kept (no-grad forwards: sampling), one call / two launches: one 16 x 16
+ * score tile per workgroup (256 workgroups at S = 256) leaves raw scaled scores and per-tile column statistics in `ws`
+ * (sdm_attn_small_nograd_workspace_bytes, no contract), the P.V launch folds the statistics and forms exp(s - m_j) / l_j
+ * while loading its operand: the probabilities never exist in memory. */
+size_t sdm_attn_small_nograd_workspace_bytes(int batch, int S);
+int sdm_attn_small_nograd(const void* qkv, int64_t ld, int batch, int S, int heads, int dk, float scale, void* res, int64_t ldr,
+                          int bf16, float* ws, size_t ws_bytes, sdm_stream_t s);
 int sdm_attn_pv_small(const void* P, int64_t ldp, const void* qkv, int64_t ld, int batch, int S, int heads, int dk, void* res,
                       int64_t ldr, int bf16, sdm_stream_t s);
 

@@ -212,6 +212,153 @@ __global__ __launch_bounds__(256) void attn_pv_small_kernel(const T* __restrict_
   }
 }
 
+// ---- no-grad form: nothing but the result is kept, so the probabilities never exist in memory ---------------------------
+// attn_scores_tile: ONE 16 x 16 score tile per workgroup (a query tile against a key block; the 16 waves split the head
+// width), written as RAW scaled scores together with the tile's column statistics {max, sum exp} per key -- 256 workgroups
+// at S = 256 instead of 16 that each pulled the whole Q matrix through one CU (34 us -> a few).
+// attn_pv_raw: folds the per-tile statistics of every key once per workgroup (S <= 256 keys: 2 KB of LDS) and forms
+// exp(s - m_j) / l_j while it loads its P operand.
+template <typename T>
+__global__ __launch_bounds__(1024) void attn_scores_tile_kernel(const T* __restrict__ qkv, long long ld, int S, int heads, int dk,
+                                                                float scale, int ksplit, float* __restrict__ raw, long long ldraw,
+                                                                float* __restrict__ pstats) {
+  __shared__ float xs[16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, img = b / heads, head = b % heads;
+  const int j0 = blockIdx.x * 16, q0 = blockIdx.y * 16, mt = gridDim.y;
+  const T* qb = qkv + (long long)img * S * ld + (long long)head * 3 * dk;
+  const T* kb = qb + dk;
+  const int li = lane & 15, kg = lane >> 4;
+  if (tid < 16 * 17) (&xs[0][0])[tid] = 0.f;
+  __syncthreads();
+  if (wave < ksplit) {
+    const int kper = dk / ksplit, kbeg = wave * kper;
+    const T* kp = kb + (long long)min(j0 + li, S - 1) * ld + kbeg + 4 * kg;
+    const T* qp = qb + (long long)min(q0 + li, S - 1) * ld + kbeg + 4 * kg;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < kper; k += 64) {          // kper is a multiple of 16
+      f32x4_t a[4], bb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k + 16 * u < kper) {
+          a[u] = load4<T>(qp + k + 16 * u);
+          bb[u] = load4<T>(kp + k + 16 * u);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k + 16 * u < kper) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], bb[u][s], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(&xs[4 * kg + r][li], acc[r]);
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int key = tid >> 4, i = tid & 15;            // 16 lanes per key: the tile's queries
+    const int q = q0 + i, j = j0 + key;
+    float v = xs[i][key] * scale;
+    asm volatile("" : "+v"(v));                        // the rounded product (see attn_scores_small_kernel)
+    if (q < S && j < S) raw[((long long)b * S + q) * ldraw + j] = v;
+    v = q < S ? v : -INFINITY;
+    float m = v;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float l = q < S ? __expf(v - m) : 0.f;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+    if (i == 0 && j < S) {
+      float* o2 = pstats + (((long long)b * S + j) * mt + blockIdx.y) * 2;      // a key's tile statistics are contiguous
+      o2[0] = m;
+      o2[1] = l;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_pv_raw_kernel(const float* __restrict__ raw, long long ldraw, const float* __restrict__ pstats,
+                                                          int mt, const T* __restrict__ qkv, long long ld, int S, int heads, int dk,
+                                                          T* __restrict__ res, long long ldr) {
+  __shared__ __attribute__((aligned(16))) float s_m[AS_MAXS], s_inv[AS_MAXS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, img = b / heads, head = b % heads;
+  for (int j = S + tid; j < AS_MAXS; j += 256) { s_m[j] = 0.f; s_inv[j] = 0.f; }      // (masked keys: exp(-inf - 0) * 0)
+  for (int j = tid; j < S; j += 256) {               // fold the per-tile statistics of key j (mt <= 16 contiguous pairs)
+    const float2* p = (const float2*)(pstats + ((long long)b * S + j) * mt * 2);
+    float2 v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = t < mt ? p[t] : make_float2(-INFINITY, 0.f);     // independent loads, one latency
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) mx = fmaxf(mx, v[t].x);
+    float sm = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sm += v[t].x > -INFINITY ? v[t].y * __expf(v[t].x - mx) : 0.f;
+    s_m[j] = mx;
+    s_inv[j] = 1.f / sm;
+  }
+  __syncthreads();
+  const int ndt = (dk + 63) >> 6;
+  const int qt = blockIdx.x / ndt, dt = blockIdx.x % ndt;
+  const int q0 = qt * 32 + (wave >> 1) * 16, d0 = dt * 64 + (wave & 1) * 32;
+  const int li = lane & 15, kg = lane >> 4;
+  if (q0 >= S || d0 >= dk) return;
+  const float* pb = raw + ((long long)b * S + min(q0 + li, S - 1)) * ldraw;
+  const T* vb = qkv + (long long)img * S * ld + (long long)head * 3 * dk + 2 * dk;
+  const int c0 = min(d0 + li, dk - 1), c1 = min(d0 + 16 + li, dk - 1);
+  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int Sk = (S + 15) & ~15;
+  // one 16-key step = one 16-byte load of raw scores (+ the keys' statistics from LDS) and eight scalar V loads feeding eight
+  // MFMAs; the loads of step j+16 are issued before the MFMAs of step j (two register sets), so the wave waits for memory
+  // once per step pair, not once per step
+  auto load_step = [&](int j, f32x4_t& rv, f32x4_t& v0, f32x4_t& v1) {      // issues loads only: nothing waits here
+    const int jj = j + 4 * kg;
+    if (jj + 3 < S) {
+      rv = *(const f32x4_t*)(pb + jj);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) rv[s] = jj + s < S ? pb[jj + s] : -INFINITY;      // exp(-inf - m) = 0
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const long long row = (long long)min(jj + s, S - 1) * ld;
+      v0[s] = load1<T>(vb + row + c0);
+      v1[s] = load1<T>(vb + row + c1);
+    }
+  };
+  auto mma_step = [&](int j, const f32x4_t& rv, const f32x4_t& v0, const f32x4_t& v1) {
+    const int jj = min(j + 4 * kg, AS_MAXS - 4);
+    const f32x4_t mv = *(const f32x4_t*)(s_m + jj), iv = *(const f32x4_t*)(s_inv + jj);
+    f32x4_t a;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = __expf(rv[s] - mv[s]) * iv[s];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], v0[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], v1[s], acc1, 0, 0, 0);
+    }
+  };
+  f32x4_t aA, vA0, vA1, aB, vB0, vB1;
+  load_step(0, aA, vA0, vA1);
+  for (int j = 0; j < Sk; j += 32) {
+    if (j + 16 < Sk) load_step(j + 16, aB, vB0, vB1);
+    mma_step(j, aA, vA0, vA1);
+    if (j + 16 < Sk) {
+      if (j + 32 < Sk) load_step(j + 32, aA, vA0, vA1);
+      mma_step(j + 16, aB, vB0, vB1);
+    }
+  }
+  T* rb = res + ((long long)img * S) * ldr + (long long)head * dk;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = q0 + 4 * kg + r;
+    if (q >= S) continue;
+    if (d0 + li < dk) store1<T>(rb + (long long)q * ldr + d0 + li, acc0[r]);
+    if (d0 + 16 + li < dk) store1<T>(rb + (long long)q * ldr + d0 + 16 + li, acc1[r]);
+  }
+}
+
 static int attn_small_check(const void* qkv, int64_t ld, int batch, int S, int heads, int dk, const void* P, int64_t ldp,
                             int elt) {
   SDM_CHECK_ARG(qkv && P && batch > 0 && heads > 0 && batch % heads == 0, "attn_small: bad args");
@@ -252,5 +399,42 @@ extern "C" int sdm_attn_pv_small(const void* P, int64_t ldp, const void* qkv, in
     hipLaunchKernelGGL(attn_pv_small_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)P, (long long)ldp,
                        (const float*)qkv, (long long)ld, S, heads, dk, (float*)res, (long long)ldr);
   SDM_CHECK_LAUNCH("attn_pv_small");
+  return SDM_OK;
+}
+
+extern "C" size_t sdm_attn_small_nograd_workspace_bytes(int batch, int S) {
+  const size_t sp = (size_t)((S + 3) & ~3), mt = (size_t)((S + 15) >> 4);
+  return ((size_t)batch * S * sp + (size_t)batch * mt * S * 2) * sizeof(float);
+}
+
+extern "C" int sdm_attn_small_nograd(const void* qkv, int64_t ld, int batch, int S, int heads, int dk, float scale, void* res,
+                                     int64_t ldr, int bf16, float* ws, size_t ws_bytes, sdm_stream_t s) {
+  SDM_CHECK_ARG(qkv && res && ws && batch > 0 && heads > 0 && batch % heads == 0, "attn_small_nograd: bad args");
+  SDM_CHECK_ARG(S > 0 && S <= AS_MAXS && dk > 0 && dk % 16 == 0, "attn_small_nograd: S <= %d, head width a multiple of 16", AS_MAXS);
+  const int elt = bf16 ? 2 : 4;
+  SDM_CHECK_ARG(ld >= 3LL * heads * dk && (ld * elt) % 16 == 0 && (((uintptr_t)qkv) & 15) == 0 && (dk * elt) % 16 == 0 &&
+                    ldr >= (int64_t)heads * dk && aligned16(ws) && ws_bytes >= sdm_attn_small_nograd_workspace_bytes(batch, S),
+                "attn_small_nograd: 16-byte aligned rows and a workspace of sdm_attn_small_nograd_workspace_bytes");
+  const int sp = (S + 3) & ~3, mt = (S + 15) >> 4;
+  float* raw = ws;
+  float* pstats = ws + (size_t)batch * S * sp;
+  int ksplit = 16;
+  while (ksplit > 1 && dk % (16 * ksplit) != 0) ksplit >>= 1;
+  dim3 g1(cdiv(S, 16), mt, batch), g2(cdiv(S, 32) * cdiv(dk, 64), batch);
+  hipStream_t st = (hipStream_t)s;
+  if (bf16) {
+    hipLaunchKernelGGL(attn_scores_tile_kernel<bf16_t>, g1, dim3(1024), 0, st, (const bf16_t*)qkv, (long long)ld, S, heads, dk, scale,
+                       ksplit, raw, (long long)sp, pstats);
+    SDM_CHECK_LAUNCH("attn_scores_tile");
+    hipLaunchKernelGGL(attn_pv_raw_kernel<bf16_t>, g2, dim3(256), 0, st, (const float*)raw, (long long)sp, (const float*)pstats, mt,
+                       (const bf16_t*)qkv, (long long)ld, S, heads, dk, (bf16_t*)res, (long long)ldr);
+  } else {
+    hipLaunchKernelGGL(attn_scores_tile_kernel<float>, g1, dim3(1024), 0, st, (const float*)qkv, (long long)ld, S, heads, dk, scale,
+                       ksplit, raw, (long long)sp, pstats);
+    SDM_CHECK_LAUNCH("attn_scores_tile");
+    hipLaunchKernelGGL(attn_pv_raw_kernel<float>, g2, dim3(256), 0, st, (const float*)raw, (long long)sp, (const float*)pstats, mt,
+                       (const float*)qkv, (long long)ld, S, heads, dk, (float*)res, (long long)ldr);
+  }
+  SDM_CHECK_LAUNCH("attn_pv_raw");
   return SDM_OK;
 }

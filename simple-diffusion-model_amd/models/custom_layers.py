@@ -353,7 +353,7 @@ class AttentionBlock(nn.Module):
                 res = ops.attention_core_fwd_bf16(qkv, x.n, S, self.heads, self.d_k)
             out = ops.linear_rows(res, self.output.weight_for(ctx), self.output.bias, res=x.t)
             return Act(out, x.n, x.h, x.w)
-        res, P = ops.attention_core_fwd(qkv, x.n, S, self.heads, self.d_k)
+        res, P = ops.attention_core_fwd(qkv, x.n, S, self.heads, self.d_k, keep_p=ctx.train)
         out = ops.linear_rows(res, self.output.weight, self.output.bias, res=x.t)
         if ctx.train:
             ctx.rec[self] = (x, qkv, P, res)

@@ -110,6 +110,8 @@ _PROTOS = {
     "sdm_col_softmax": (_i, [fp, _i, _i, _i64, fp]),
     "sdm_col_softmax_bwd": (_i, [fp, fp, _i, _i, _i64, _f, fp]),
     "sdm_attn_scores_small": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, _i64, _i, fp]),
+    "sdm_attn_small_nograd_workspace_bytes": (_sz, [_i, _i]),
+    "sdm_attn_small_nograd": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, _i64, _i, fp, _sz, fp]),
     "sdm_attn_pv_small": (_i, [fp, _i64, fp, _i64, _i, _i, _i, _i, fp, _i64, _i, fp]),
     "sdm_sinusoid": (_i, [fp, fp, _i, _i, fp, fp]),
     "sdm_linear_small": (_i, [fp, _i64, fp, fp, fp, _i64, _i, fp, _i64, fp, _i, _i, _i, _i, fp]),

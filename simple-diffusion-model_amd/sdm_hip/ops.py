@@ -503,6 +503,7 @@ TWO_PASS_ATTN = [os.environ.get("SDM_ATTN_TWOPASS", "1") != "0"]   # bf16 rows, 
 TWO_PASS_MAX_DK = 512    # measured (tools/attn_probe.py): at head width 512 the second scores GEMM costs less than the fp32
                          # round trip + softmax pass it replaces (8 x 4096 tokens: 823 -> 697 us; 128 x 1024: 923 -> 854;
                          # 32 x 1024: 228 -> 214); at 1024 it costs more (16 x 1024: 166 -> 181 us)
+NOGRAD_ATTN = [os.environ.get("SDM_NOGRAD_ATTN", "1") != "0"]   # short sequences, no-grad: probabilities never written
 SMALL_ATTN = [os.environ.get("SDM_SMALL_ATTN", "1") != "0"]     # short sequences: the two-launch core of sdm_attn.hip
 SMALL_ATTN_MAX_S = 256
 
@@ -511,10 +512,18 @@ def _small_attn_ok(qkv, S, dk):
     return SMALL_ATTN[0] and S <= SMALL_ATTN_MAX_S and dk % 16 == 0 and qkv.stride(0) % 8 == 0
 
 
-def attention_core_small(qkv, n, S, heads, dk, Sp):
+def attention_core_small(qkv, n, S, heads, dk, Sp, need_p=True):
     """Attention core of a short sequence in two launches (scores + column softmax on chip; P.V): returns (res, P) in the
-    rows' type with P laid out [n*heads, S, Sp] exactly as the generic path leaves it (the training backward keeps it)."""
+    rows' type with P laid out [n*heads, S, Sp] exactly as the generic path leaves it (the training backward keeps it).
+    ``need_p=False`` (no-grad forwards): the tile-per-workgroup form that never writes the probabilities; returns (res, None)."""
     dev, bf = qkv.device, int(qkv.dtype == BF16)
+    if not need_p and NOGRAD_ATTN[0]:
+        res = torch.empty((n * S, heads * dk), dtype=qkv.dtype, device=dev)
+        nb = lib.raw("sdm_attn_small_nograd_workspace_bytes")(n * heads, S)
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+        lib.call("sdm_attn_small_nograd", _p(qkv), qkv.stride(0), n * heads, S, heads, dk, float(dk) ** -0.5, _p(res), res.stride(0), bf,
+                 _p(ws), nb, _stream())
+        return res, None
     P = torch.empty((n * heads, S, Sp), dtype=qkv.dtype, device=dev)
     res = torch.empty((n * S, heads * dk), dtype=qkv.dtype, device=dev)
     st = _stream()
@@ -523,14 +532,15 @@ def attention_core_small(qkv, n, S, heads, dk, Sp):
     return res, P
 
 
-def attention_core_fwd(qkv, n, S, heads, dk):
+def attention_core_fwd(qkv, n, S, heads, dk, keep_p=True):
     """qkv: [n*S, heads*3*dk] with per-head [q|k|v] chunks (custom_layers.py:138-141).
-    Returns (res [n*S, heads*dk], P [n*heads, S, Sp]) with P the column-softmaxed scores."""
+    Returns (res [n*S, heads*dk], P [n*heads, S, Sp]) with P the column-softmaxed scores (None when ``keep_p`` is False and
+    the short-sequence no-grad form ran)."""
     dev = qkv.device
     Sp = _pad4(S)
     ld = qkv.stride(0)
     if _small_attn_ok(qkv, S, dk):
-        return attention_core_small(qkv, n, S, heads, dk, Sp)
+        return attention_core_small(qkv, n, S, heads, dk, Sp, need_p=keep_p)
     P = torch.empty((n * heads, S, Sp), dtype=torch.float32, device=dev)
     d = _base_desc(S, S, dk)
     d.batch, d.bdiv = n * heads, heads
@@ -572,7 +582,7 @@ def attention_core_fwd_bf16(qkv, n, S, heads, dk, keep_p=False):
     Sp = _pad8(S)
     ld = qkv.stride(0)
     if _small_attn_ok(qkv, S, dk):
-        res, P = attention_core_small(qkv, n, S, heads, dk, Sp)
+        res, P = attention_core_small(qkv, n, S, heads, dk, Sp, need_p=keep_p)
         return (res, P) if keep_p else res
     B = n * heads
 

@@ -1066,6 +1066,14 @@ def test_short_sequence_attention_core(dev, n, S, heads, dk, bf16):
         ops.SMALL_ATTN[0] = True
     assert rel(res.float(), res2.float()) < (1.5e-2 if bf16 else 2e-5)
     assert P2.shape == P.shape and P2.dtype == P.dtype
+    # no-grad form (sdm_attn_small_nograd: one score tile per workgroup, probabilities never written)
+    res3, P3 = ops.attention_core_small(x, n, S, heads, dk, Sp, need_p=False)
+    assert P3 is None and rel(res3.float(), want) < tolR, rel(res3.float(), want)
+    if not bf16:
+        big = (torch.randn(n * S, heads * 3 * dk, generator=g) * 1e7).to(dev)
+        r3, _ = ops.attention_core_small(big, n, S, heads, dk, Sp, need_p=False)
+        r4, _ = ops.attention_core_small(big, n, S, heads, dk, Sp)
+        assert bool(torch.isfinite(r3).all()) and rel(r3, r4) < 1e-4
     if not bf16:
         # logits of 1e13..1e17 (an untrained net under classifier-free guidance reaches them): the scaled score must be
         # rounded before the column maximum is subtracted, or the maximum itself becomes exp(rounding error) = inf
