@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
   constexpr int A_TILE = BM * ROWF, B_TILE = BN * ROWF;
   constexpr int G = AIT + BIT;
   constexpr int PD = NBUF - 1;
-  static_assert(PD >= 1 && PD <= 3, "ring depth");
+  static_assert(PD >= 1 && PD <= 5, "ring depth");
   extern __shared__ __align__(16) float smem[];
   float* As = smem;
   float* Bs = smem + NBUF * A_TILE;
@@ -252,7 +252,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
   for (int it = it0; it < it1; ++it) {
     const int buf = (it - it0) % NBUF;
     const int younger = (it1 - 1 - it) < (PD - 1) ? (it1 - 1 - it) : (PD - 1);
-    if (younger >= 2) wait_vmcnt_bf<2 * G>();
+    if (PD >= 5 && younger >= 4) wait_vmcnt_bf<(PD >= 5 ? 4 : 0) * G>();
+    else if (PD >= 4 && younger == 3) wait_vmcnt_bf<(PD >= 4 ? 3 : 0) * G>();
+    else if (younger >= 2) wait_vmcnt_bf<2 * G>();
     else if (younger == 1) wait_vmcnt_bf<G>();
     else wait_vmcnt_bf<0>();
     __builtin_amdgcn_s_barrier();   // tile `it` visible to all waves; ring slot of tile it-1 is free again
@@ -1084,7 +1086,16 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
     }
   }
   if (cfg == 0) rc = fast ? launch_bf<128, 128, 2, 2, 2, true>(L, ntm, st) : launch_bf<128, 128, 2, 2, 2, false>(L, ntm, st);
-  else if (cfg == 1) rc = fast ? launch_bf<64, 64, 2, 2, 3, true>(L, ntm, st) : launch_bf<64, 64, 2, 2, 3, false>(L, ntm, st);
+  else if (cfg == 1) {
+    // EXPERIMENT, opt-in (SDM_BF16_DEEP=1): at most one workgroup per CU in the grid (the N=1..4 sampling step) -> ring 6
+    // (96 KB, five K-steps in flight instead of two).  Measured neutral on MI355X (N=1 bf16 step 0.727 -> 0.732 ms, N=4
+    // 0.937 -> 0.957): these launches are not bound by tile-fetch latency per K-step but by the fixed chain of a launch
+    // (kernel-argument / table / first-tile / store-drain round trips, ~7 us whatever the K walk; tools/scratch/tiny_igemm.py).
+    static const char* deep = getenv("SDM_BF16_DEEP");
+    const long nblocks = (long)ntm * L.ntn * d->nphase * L.splitk * d->batch;
+    if (fast && nblocks <= 256 && deep && deep[0] == '1') rc = launch_bf<64, 64, 2, 2, 6, true>(L, ntm, st);
+    else rc = fast ? launch_bf<64, 64, 2, 2, 3, true>(L, ntm, st) : launch_bf<64, 64, 2, 2, 3, false>(L, ntm, st);
+  }
   else if (cfg == 2 && fast && L.vec_epi && L.splitk == 1) rc = launch_bf<256, 256, 2, 4, 2, true>(L, ntm, st);
   else if (cfg == 3 && fast && L.vec_epi && L.splitk == 1) rc = launch_bf<256, 256, 4, 2, 2, true>(L, ntm, st);
   else rc = sdm_set_error(SDM_ERR_ARG, "igemm_bf16: tile configuration %d needs the FAST path, the vector epilogue and no split-K", cfg);
