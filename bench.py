@@ -177,10 +177,11 @@ def other_configs(dev, sched, net64):
     for n in (1, 4):
         for dt, b, peak in ((torch.float32, 4, PEAK_FP32_MFMA_TFLOPS), (torch.bfloat16, 2, PEAK_BF16_MFMA_TFLOPS)):
             net64.set_inference_dtype(dt)
-            ms, launches = sample_ms(net64, n, 200)
+            ms, launches = sample_ms(net64, n, 1000)
             rec = fractions(ms, FWD_FLOPS_PER_IMAGE[64] * n, alg_bytes(n, 64, b, False), peak)
             rec.update(dtype="f32" if b == 4 else "bf16", batch=n, launches_per_step=launches,
-                       what="DDPM step (U-Net forward + update) replayed from a hipGraph, 200 steps incl. one capture")
+                       what="DDPM step (U-Net forward + update) replayed from a hipGraph: the whole T=1000 sampling run incl. its "
+                            "one capture (BASELINE configs[1] 'DDPM T=1000 sample'), per step")
             out["c2_sample_n%d_%s" % (n, "fp32" if b == 4 else "bf16")] = rec
     net64.set_inference_dtype(torch.float32)
 

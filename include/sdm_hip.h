@@ -58,6 +58,20 @@ int sdm_stream_order(sdm_stream_t from, sdm_stream_t to);
  * difference over one step as launches_per_step. */
 unsigned long long sdm_launch_count(void);
 
+/* Launch plans: record the library's kernel launches once, replay them from C (SURVEY 8b "who calls the C ABI": the
+ * samplers' captured step; VERDICT r2 "C-side launch plan").  Between sdm_plan_begin and sdm_plan_end every launch the
+ * library issues -- eagerly, or into a stream capture -- is also appended to the plan with a copy of its argument VALUES
+ * (device pointers included: the caller keeps those buffers alive and in place, e.g. by holding the hipGraph captured over
+ * the same calls, whose memory pool owns them).  sdm_plan_end returns the handle (>= 1), or 0 when something ran that a
+ * plan cannot replay (a memset inside the library): the recording is dropped.  sdm_plan_run re-issues the sequence
+ * `repeat` times on `stream` with plain launches (no graph): a step whose only per-step state lives in device memory (the
+ * samplers' cursor and tables) is replayed with ONE call.  Single-threaded, one recording at a time. */
+int sdm_plan_begin(void);
+int sdm_plan_end(void);
+int sdm_plan_launches(int handle);
+int sdm_plan_run(int handle, int repeat, sdm_stream_t stream);
+int sdm_plan_free(int handle);
+
 /* Per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg; not capturable, so
  * keep it off inside hipGraph capture).  Classes: 0 igemm 128x128, 1 igemm 64x64, 2 igemm 32x128,
  * 3 wgrad 128x128, 4 wgrad 64x64, 5 igemm 128x64, 6 skinny-M weight streaming.  sdm_prof_begin(cap) arms it for up to cap launches; sdm_prof_end

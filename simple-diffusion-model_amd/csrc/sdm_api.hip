@@ -32,6 +32,87 @@ extern "C" int sdm_device_info(int* out4) {
   return SDM_OK;
 }
 
+// ---- launch plans -------------------------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct PlanRec { const void* fn; dim3 grid, block; unsigned lds; int nargs; size_t blob_off; unsigned arg_off[32]; };
+struct Plan { std::vector<PlanRec> recs; std::vector<unsigned char> blob; bool tainted = false; char why[64] = ""; bool live = false; };
+std::vector<Plan*> g_plans;
+Plan* g_rec = nullptr;
+}  // namespace
+
+bool sdm_plan_recording() { return g_rec != nullptr; }
+void sdm_plan_taint(const char* why) {
+  if (g_rec && !g_rec->tainted) {
+    g_rec->tainted = true;
+    snprintf(g_rec->why, sizeof(g_rec->why), "%s", why);
+  }
+}
+void sdm_plan_push(const void* fn, dim3 grid, dim3 block, size_t lds, void** args, const size_t* sizes, int nargs) {
+  if (!g_rec) return;
+  if (nargs > 32) { sdm_plan_taint("more than 32 kernel arguments"); return; }
+  PlanRec r;
+  r.fn = fn; r.grid = grid; r.block = block; r.lds = (unsigned)lds; r.nargs = nargs;
+  size_t off = (g_rec->blob.size() + 15) & ~(size_t)15;
+  r.blob_off = off;
+  size_t need = off;
+  for (int i = 0; i < nargs; ++i) {
+    need = (need + 15) & ~(size_t)15;             // every argument 16-byte aligned inside the blob
+    r.arg_off[i] = (unsigned)(need - off);
+    need += sizes[i];
+  }
+  g_rec->blob.resize(need);
+  for (int i = 0; i < nargs; ++i) memcpy(g_rec->blob.data() + off + r.arg_off[i], args[i], sizes[i]);
+  g_rec->recs.push_back(r);
+}
+
+extern "C" int sdm_plan_begin(void) {
+  SDM_CHECK_ARG(g_rec == nullptr, "plan_begin: a plan is already being recorded");
+  g_rec = new Plan();
+  return SDM_OK;
+}
+// Ends the recording.  Returns the plan's handle (>= 1), or 0 when something ran that a plan cannot replay (the
+// recording is dropped; sdm_last_error() names it) -- the caller then keeps replaying its hipGraph.
+extern "C" int sdm_plan_end(void) {
+  SDM_CHECK_ARG(g_rec != nullptr, "plan_end: no plan is being recorded");
+  Plan* p = g_rec;
+  g_rec = nullptr;
+  if (p->tainted || p->recs.empty()) {
+    (void)sdm_set_error(0, "plan dropped: %s", p->tainted ? p->why : "no launches");
+    delete p;
+    return 0;
+  }
+  p->live = true;
+  for (size_t i = 0; i < g_plans.size(); ++i)
+    if (g_plans[i] == nullptr) { g_plans[i] = p; return (int)i + 1; }
+  g_plans.push_back(p);
+  return (int)g_plans.size();
+}
+extern "C" int sdm_plan_launches(int handle) {
+  SDM_CHECK_ARG(handle >= 1 && handle <= (int)g_plans.size() && g_plans[handle - 1], "plan_launches: bad handle");
+  return (int)g_plans[handle - 1]->recs.size();
+}
+extern "C" int sdm_plan_run(int handle, int repeat, sdm_stream_t stream) {
+  SDM_CHECK_ARG(handle >= 1 && handle <= (int)g_plans.size() && g_plans[handle - 1] && repeat >= 1, "plan_run: bad handle");
+  Plan* p = g_plans[handle - 1];
+  void* ptrs[32];
+  for (int rep = 0; rep < repeat; ++rep)
+    for (const PlanRec& r : p->recs) {
+      unsigned char* base = p->blob.data() + r.blob_off;
+      for (int i = 0; i < r.nargs; ++i) ptrs[i] = base + r.arg_off[i];
+      if (hipLaunchKernel(r.fn, r.grid, r.block, ptrs, r.lds, (hipStream_t)stream) != hipSuccess)
+        return sdm_set_error(SDM_ERR_LAUNCH, "plan_run: %s", hipGetErrorString(hipGetLastError()));
+    }
+  g_sdm_launches += (unsigned long long)repeat * p->recs.size();
+  return SDM_OK;
+}
+extern "C" int sdm_plan_free(int handle) {
+  SDM_CHECK_ARG(handle >= 1 && handle <= (int)g_plans.size() && g_plans[handle - 1], "plan_free: bad handle");
+  delete g_plans[handle - 1];
+  g_plans[handle - 1] = nullptr;
+  return SDM_OK;
+}
+
 // sizes of the ABI structs, so a binding can assert its own layout (0: igemm desc, 1: wgrad desc, 2: rows,
 // 3: linear job, 4: adam job)
 // ring of timing-free events for sdm_stream_order (a wait captures the record that precedes it, so re-recording an

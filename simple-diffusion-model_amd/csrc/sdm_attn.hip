@@ -377,10 +377,10 @@ extern "C" int sdm_attn_scores_small(const void* qkv, int64_t ld, int batch, int
   if (rc != SDM_OK) return rc;
   dim3 grid(cdiv(bf16 ? (ldp < ((S + 15) & ~15) ? ldp : ((S + 15) & ~15)) : S, AS_KB), batch);
   if (bf16)
-    hipLaunchKernelGGL(attn_scores_small_kernel<bf16_t>, grid, dim3(64 * AS_WAVES), 0, (hipStream_t)s, (const bf16_t*)qkv,
+    SDM_LAUNCH(attn_scores_small_kernel<bf16_t>, grid, dim3(64 * AS_WAVES), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (long long)ld, S, heads, dk, scale, (bf16_t*)P, (long long)ldp);
   else
-    hipLaunchKernelGGL(attn_scores_small_kernel<float>, grid, dim3(64 * AS_WAVES), 0, (hipStream_t)s, (const float*)qkv,
+    SDM_LAUNCH(attn_scores_small_kernel<float>, grid, dim3(64 * AS_WAVES), 0, (hipStream_t)s, (const float*)qkv,
                        (long long)ld, S, heads, dk, scale, (float*)P, (long long)ldp);
   SDM_CHECK_LAUNCH("attn_scores_small");
   return SDM_OK;
@@ -393,10 +393,10 @@ extern "C" int sdm_attn_pv_small(const void* P, int64_t ldp, const void* qkv, in
   SDM_CHECK_ARG(res && ldr >= (int64_t)heads * dk, "attn_pv_small: bad output");
   dim3 grid(cdiv(S, 32) * cdiv(dk, 64), batch);
   if (bf16)
-    hipLaunchKernelGGL(attn_pv_small_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)P, (long long)ldp,
+    SDM_LAUNCH(attn_pv_small_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)P, (long long)ldp,
                        (const bf16_t*)qkv, (long long)ld, S, heads, dk, (bf16_t*)res, (long long)ldr);
   else
-    hipLaunchKernelGGL(attn_pv_small_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)P, (long long)ldp,
+    SDM_LAUNCH(attn_pv_small_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)P, (long long)ldp,
                        (const float*)qkv, (long long)ld, S, heads, dk, (float*)res, (long long)ldr);
   SDM_CHECK_LAUNCH("attn_pv_small");
   return SDM_OK;
@@ -423,16 +423,16 @@ extern "C" int sdm_attn_small_nograd(const void* qkv, int64_t ld, int batch, int
   dim3 g1(cdiv(S, 16), mt, batch), g2(cdiv(S, 32) * cdiv(dk, 64), batch);
   hipStream_t st = (hipStream_t)s;
   if (bf16) {
-    hipLaunchKernelGGL(attn_scores_tile_kernel<bf16_t>, g1, dim3(1024), 0, st, (const bf16_t*)qkv, (long long)ld, S, heads, dk, scale,
+    SDM_LAUNCH(attn_scores_tile_kernel<bf16_t>, g1, dim3(1024), 0, st, (const bf16_t*)qkv, (long long)ld, S, heads, dk, scale,
                        ksplit, raw, (long long)sp, pstats);
     SDM_CHECK_LAUNCH("attn_scores_tile");
-    hipLaunchKernelGGL(attn_pv_raw_kernel<bf16_t>, g2, dim3(256), 0, st, (const float*)raw, (long long)sp, (const float*)pstats, mt,
+    SDM_LAUNCH(attn_pv_raw_kernel<bf16_t>, g2, dim3(256), 0, st, (const float*)raw, (long long)sp, (const float*)pstats, mt,
                        (const bf16_t*)qkv, (long long)ld, S, heads, dk, (bf16_t*)res, (long long)ldr);
   } else {
-    hipLaunchKernelGGL(attn_scores_tile_kernel<float>, g1, dim3(1024), 0, st, (const float*)qkv, (long long)ld, S, heads, dk, scale,
+    SDM_LAUNCH(attn_scores_tile_kernel<float>, g1, dim3(1024), 0, st, (const float*)qkv, (long long)ld, S, heads, dk, scale,
                        ksplit, raw, (long long)sp, pstats);
     SDM_CHECK_LAUNCH("attn_scores_tile");
-    hipLaunchKernelGGL(attn_pv_raw_kernel<float>, g2, dim3(256), 0, st, (const float*)raw, (long long)sp, (const float*)pstats, mt,
+    SDM_LAUNCH(attn_pv_raw_kernel<float>, g2, dim3(256), 0, st, (const float*)raw, (long long)sp, (const float*)pstats, mt,
                        (const float*)qkv, (long long)ld, S, heads, dk, (float*)res, (long long)ldr);
   }
   SDM_CHECK_LAUNCH("attn_pv_raw");

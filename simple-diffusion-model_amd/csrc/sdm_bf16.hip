@@ -923,7 +923,7 @@ static int launch_bf(const BfLaunch& L, int ntm, hipStream_t st) {
     sdm_prof_shape(L.d.M, L.d.N, L.d.K, (int)taps, L.splitk, 2.0 * L.d.batch * (in_b + w_b + out_b));
   }
   sdm_prof_pre(st);
-  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, L);
+  SDM_LAUNCH(kern, grid, dim3(64 * WM * WN), lds, st, L);
   sdm_prof_post(st, BM >= 128 ? 0 : 1, 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
   SDM_CHECK_LAUNCH("igemm_bf16");
   return SDM_OK;
@@ -972,7 +972,7 @@ static int launch_row(const sdm_igemm_desc* d, RowLaunch& R, int gn_stats, hipSt
     sdm_prof_shape(d->M, d->N, d->K, 9, 1, 2.0 * (in_b + w_b + out_b));
   }
   sdm_prof_pre(st);
-  hipLaunchKernelGGL(kern, dim3((d->M / BM) * R.ntn), dim3(64 * WM * WN), lds, st, R);
+  SDM_LAUNCH(kern, dim3((d->M / BM) * R.ntn), dim3(64 * WM * WN), lds, st, R);
   sdm_prof_post(st, 0, 2.0 * d->M * d->N * d->K * 9);
   SDM_CHECK_LAUNCH("conv3_row_bf16");
   return SDM_OK;
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(256) void colstats_combine_kernel(const float* __re
 extern "C" int sdm_attn_colstats_combine(const float* col_stats, int batch, int ntiles, int N, float* neg_max, float* inv_sum,
                                          sdm_stream_t s) {
   SDM_CHECK_ARG(col_stats && neg_max && inv_sum && batch > 0 && ntiles > 0 && N > 0, "attn_colstats_combine: bad args");
-  hipLaunchKernelGGL(colstats_combine_kernel, dim3(cdiv(N, 256), batch), dim3(256), 0, (hipStream_t)s, col_stats, ntiles, N,
+  SDM_LAUNCH(colstats_combine_kernel, dim3(cdiv(N, 256), batch), dim3(256), 0, (hipStream_t)s, col_stats, ntiles, N,
                      neg_max, inv_sum);
   SDM_CHECK_LAUNCH("attn_colstats_combine");
   return SDM_OK;
@@ -1108,7 +1108,7 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
     int grid = (int)((total + 1023) / 1024);
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(splitk_epilogue_bf16_kernel, dim3(grid), dim3(256), 0, st, *d, (long long)out_rows, L.out_f32);
+    SDM_LAUNCH(splitk_epilogue_bf16_kernel, dim3(grid), dim3(256), 0, st, *d, (long long)out_rows, L.out_f32);
     SDM_CHECK_LAUNCH("splitk_epilogue_bf16");
   }
   return SDM_OK;
@@ -1138,7 +1138,7 @@ extern "C" int sdm_cast_bf16(const float* src, uint16_t* dst, size_t n, sdm_stre
   const int vec = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
   size_t grid = ((vec ? n / 8 + 1 : n) + 255) / 256;
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)s, src, dst, n, vec);
+  SDM_LAUNCH(cast_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)s, src, dst, n, vec);
   SDM_CHECK_LAUNCH("cast_bf16");
   return SDM_OK;
 }
@@ -1194,7 +1194,7 @@ extern "C" int sdm_stem_conv_bf16(const float* x, const float* w, const float* b
   SDM_CHECK_ARG(Cin >= 1 && Cin <= 8, "stem_conv_bf16: Cin %d not in [1,8]", Cin);
   const long long P = (long long)images * H * W;
   const dim3 grid(cdiv(P, STEM_PIX_BF));
-#define STEM_BF(C) hipLaunchKernelGGL(stem_conv_bf16_kernel<C>, grid, dim3(256), 0, (hipStream_t)s, x, w, bias, out, out_preact, images, H, W, Cout, act)
+#define STEM_BF(C) SDM_LAUNCH(stem_conv_bf16_kernel<C>, grid, dim3(256), 0, (hipStream_t)s, x, w, bias, out, out_preact, images, H, W, Cout, act)
   switch (Cin) {
     case 1: STEM_BF(1); break;
     case 2: STEM_BF(2); break;
@@ -1248,7 +1248,7 @@ extern "C" int sdm_head_conv_bf16(const uint16_t* x, const float* w, const float
   int g = (int)((P + 3) / 4);
   if (g > 8192) g = 8192;
   const dim3 grid(g);
-#define HEAD_BF(C) hipLaunchKernelGGL(head_conv_bf16_kernel<C>, grid, dim3(256), 0, (hipStream_t)s, x, w, bias, out, images, Cin, H, W, act)
+#define HEAD_BF(C) SDM_LAUNCH(head_conv_bf16_kernel<C>, grid, dim3(256), 0, (hipStream_t)s, x, w, bias, out, images, Cin, H, W, act)
   switch (Cout) {
     case 1: HEAD_BF(1); break;
     case 2: HEAD_BF(2); break;
@@ -1341,7 +1341,7 @@ extern "C" int sdm_gn_affine_bf16(const uint16_t* y, int64_t ldy, int images, in
   SDM_CHECK_ARG(y && gamma && beta && scale && shift && (mean == nullptr) == (rstd == nullptr), "gn_affine_bf16: null pointer");
   SDM_CHECK_ARG(images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_affine_bf16: C %d not divisible by groups %d", C, groups);
   const int vec = ((C / groups) % 4 == 0) && ldy % 4 == 0 && (((uintptr_t)y) & 7) == 0;
-  hipLaunchKernelGGL(gn_affine_bf16_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, y, (long long)ldy, HW, C,
+  SDM_LAUNCH(gn_affine_bf16_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, y, (long long)ldy, HW, C,
                      groups, eps, gamma, beta, mod, mod_nstride, scale, shift, mean, rstd, vec);
   SDM_CHECK_LAUNCH("gn_affine_bf16");
   return SDM_OK;
@@ -1401,7 +1401,7 @@ extern "C" int sdm_affine_residual_bf16(const uint16_t* y, int64_t ldy, const fl
   const long long work = rows * (C / 8);
   int grid = (int)((work + 255) / 256);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(affine_residual_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, y, (long long)ldy, scale, shift,
+  SDM_LAUNCH(affine_residual_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, y, (long long)ldy, scale, shift,
                      aff_nstride, x0, (long long)ldx0, x1, (long long)ldx1, csplit, out, (long long)ldo, rows, HW, C);
   SDM_CHECK_LAUNCH("affine_residual_bf16");
   return SDM_OK;
@@ -1475,7 +1475,7 @@ __global__ __launch_bounds__(64 * CSM_W) void col_softmax_bf16_kernel(const floa
 extern "C" int sdm_col_softmax_bf16(const float* scores, uint16_t* P, int batch, int S, int64_t lds, int64_t ldp,
                                     sdm_stream_t s) {
   SDM_CHECK_ARG(scores && P && batch > 0 && S > 0 && lds >= S && ldp >= S, "col_softmax_bf16: bad args");
-  hipLaunchKernelGGL(col_softmax_bf16_kernel, dim3(cdiv(ldp, 64), batch), dim3(64 * CSM_W), 0, (hipStream_t)s, scores, P, S,
+  SDM_LAUNCH(col_softmax_bf16_kernel, dim3(cdiv(ldp, 64), batch), dim3(64 * CSM_W), 0, (hipStream_t)s, scores, P, S,
                      (long long)lds, (long long)ldp);
   SDM_CHECK_LAUNCH("col_softmax_bf16");
   return SDM_OK;
@@ -1508,7 +1508,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 extern "C" int sdm_transpose_bf16(const uint16_t* src, int64_t ld_src, int64_t src_bs0, int64_t src_bs1, int bdiv,
                                   uint16_t* dst, int64_t ld_dst, int64_t dst_bs, int batch, int R, int Cc, sdm_stream_t s) {
   SDM_CHECK_ARG(src && dst && batch > 0 && bdiv > 0 && R > 0 && Cc > 0 && ld_dst >= R && ld_src >= Cc, "transpose_bf16: bad args");
-  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(cdiv(Cc, 64), cdiv(ld_dst, 64), batch), dim3(256), 0, (hipStream_t)s, src,
+  SDM_LAUNCH(transpose_bf16_kernel, dim3(cdiv(Cc, 64), cdiv(ld_dst, 64), batch), dim3(256), 0, (hipStream_t)s, src,
                      (long long)ld_src, (long long)src_bs0, (long long)src_bs1, bdiv, dst, (long long)ld_dst,
                      (long long)dst_bs, R, Cc);
   SDM_CHECK_LAUNCH("transpose_bf16");
@@ -1532,7 +1532,7 @@ extern "C" int sdm_rows_to_nchw(const float* rows, int64_t ld, float* out_nchw, 
   const long long HW = (long long)H * W, P = HW * images;
   int grid = (int)((P + 255) / 256);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(rows_to_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, rows, (long long)ld, out_nchw, C, HW, P);
+  SDM_LAUNCH(rows_to_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, rows, (long long)ld, out_nchw, C, HW, P);
   SDM_CHECK_LAUNCH("rows_to_nchw");
   return SDM_OK;
 }
@@ -1654,7 +1654,7 @@ extern "C" int sdm_gn_apply_fused_bf16(const void* src, int64_t ld_src, int src_
                     (x1 == nullptr || (al(x1, 8) && ldx1 % 4 == 0)),
                 "gn_apply_fused_bf16: needs channels-per-group %% 4 == 0 and aligned rows / tables");
   SDM_CHECK_ARG(act >= 0 && act <= 2, "gn_apply_fused_bf16: bad act");
-  hipLaunchKernelGGL(gn_apply_fused_bf16_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, (void*)src,
+  SDM_LAUNCH(gn_apply_fused_bf16_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, (void*)src,
                      (long long)ld_src, src_raw, alpha, bias, act, HW, C, groups, eps, gamma, beta, mod, mod_nstride,
                      (const bf16_t*)x0, (long long)ldx0, (const bf16_t*)x1, (long long)ldx1, csplit, (bf16_t*)out, (long long)ldo);
   SDM_CHECK_LAUNCH("gn_apply_fused_bf16");
@@ -1708,7 +1708,7 @@ extern "C" int sdm_gn_finalize(float* sums, int images, int HW, int C, int group
                                float* rstd, sdm_stream_t s) {
   SDM_CHECK_ARG(sums && gamma && beta && scale && shift && (mean == nullptr) == (rstd == nullptr), "gn_finalize: null pointer");
   SDM_CHECK_ARG(images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_finalize: C %d not divisible by groups %d", C, groups);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(images * groups), dim3(64), 0, (hipStream_t)s, sums, HW, C, groups, eps, gamma,
+  SDM_LAUNCH(gn_finalize_kernel, dim3(images * groups), dim3(64), 0, (hipStream_t)s, sums, HW, C, groups, eps, gamma,
                      beta, mod, mod_nstride, scale, shift, mean, rstd);
   SDM_CHECK_LAUNCH("gn_finalize");
   return SDM_OK;

@@ -304,7 +304,7 @@ static int launch_wgrad_bf16(const WgradBfLaunch& L, int ntm, hipStream_t st) {
                    L.d.batch * (2.0 * (g_b + x_b) + 4.0 * w_b));
   }
   sdm_prof_pre(st);
-  hipLaunchKernelGGL((wgrad_bf16_kernel<BT, WM, WN, NBUF, FASTP>), grid, dim3(64 * WM * WN), lds, st, L);
+  SDM_LAUNCH((wgrad_bf16_kernel<BT, WM, WN, NBUF, FASTP>), grid, dim3(64 * WM * WN), lds, st, L);
   sdm_prof_post(st, BT >= 128 ? 3 : 4, 2.0 * L.d.M * L.d.N * (double)L.d.images * L.d.Hk * L.d.Wk * L.d.ntaps * L.d.batch);
   SDM_CHECK_LAUNCH("wgrad_bf16");
   return SDM_OK;
@@ -644,7 +644,7 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
     for (int b = 0; b < d->batch; ++b)
       for (int t = 0; t < d->ntaps; ++t) {
         float* p = d->dw + (b / d->bdiv) * d->w_bs0 + (b % d->bdiv) * d->w_bs1 + (long long)d->tap_w[t] * d->w_tap_stride;
-        hipLaunchKernelGGL(zero_rows_f32_kernel, dim3(cdiv((long)d->M * d->N, 1024)), dim3(256), 0, st, p, (long long)d->M, d->N,
+        SDM_LAUNCH(zero_rows_f32_kernel, dim3(cdiv((long)d->M * d->N, 1024)), dim3(256), 0, st, p, (long long)d->M, d->N,
                            (long long)d->ldw);
         SDM_CHECK_LAUNCH("zero_rows");
       }
@@ -669,9 +669,9 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
     }
     sdm_prof_pre(st);
     const dim3 grid3(cdiv(d->M, 128) * L3.ntn * sk, 3, 1);
-    if (d->Wk >= 64) hipLaunchKernelGGL(wgrad3_bf16_kernel<6>, grid3, dim3(256), lds3, st, L3);
-    else if (d->Wk == 32) hipLaunchKernelGGL(wgrad3_bf16_kernel<5>, grid3, dim3(256), lds3, st, L3);
-    else hipLaunchKernelGGL(wgrad3_bf16_kernel<4>, grid3, dim3(256), lds3, st, L3);
+    if (d->Wk >= 64) SDM_LAUNCH(wgrad3_bf16_kernel<6>, grid3, dim3(256), lds3, st, L3);
+    else if (d->Wk == 32) SDM_LAUNCH(wgrad3_bf16_kernel<5>, grid3, dim3(256), lds3, st, L3);
+    else SDM_LAUNCH(wgrad3_bf16_kernel<4>, grid3, dim3(256), lds3, st, L3);
     sdm_prof_post(st, 3, 2.0 * d->M * d->N * (double)P * 9);
     SDM_CHECK_LAUNCH("wgrad3_bf16");
     return SDM_OK;
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restric
 
 extern "C" int sdm_cast_bf16_t(const float* src, uint16_t* dst, int T, int R, int Cc, int ldd, sdm_stream_t s) {
   SDM_CHECK_ARG(src && dst && T > 0 && R > 0 && Cc > 0 && ldd >= R, "cast_bf16_t: bad args");
-  hipLaunchKernelGGL(cast_bf16_t_kernel, dim3(cdiv(Cc, 64), cdiv(ldd, 64), T), dim3(256), 0, (hipStream_t)s, src, dst, R, Cc, ldd);
+  SDM_LAUNCH(cast_bf16_t_kernel, dim3(cdiv(Cc, 64), cdiv(ldd, 64), T), dim3(256), 0, (hipStream_t)s, src, dst, R, Cc, ldd);
   SDM_CHECK_LAUNCH("cast_bf16_t");
   return SDM_OK;
 }
@@ -825,7 +825,7 @@ extern "C" int sdm_gn_adagn_bwd_bf16(const uint16_t* dout, int64_t lddo, const u
   hipStream_t st = (hipStream_t)s;
   int rpb = (HW + 63) / 64;
   if (rpb < 8) rpb = 8;
-  hipLaunchKernelGGL(gn_bwd_sums_bf16_kernel, dim3(cdiv(HW, rpb), images), dim3(256), 0, st, dout, (long long)lddo, y,
+  SDM_LAUNCH(gn_bwd_sums_bf16_kernel, dim3(cdiv(HW, rpb), images), dim3(256), 0, st, dout, (long long)lddo, y,
                      (long long)ldy, HW, C, rpb, ws);
   SDM_CHECK_LAUNCH("gn_bwd_sums_bf16");
   int rc = sdm_launch_gn_bwd_coef(ws, images, HW, C, groups, gamma, beta, mod, mod_nstride, mean, rstd, coef, dmod, dgamma,
@@ -835,7 +835,7 @@ extern "C" int sdm_gn_adagn_bwd_bf16(const uint16_t* dout, int64_t lddo, const u
   const long long work = rows * (C / 8);
   int grid = (int)((work + 255) / 256);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(gn_bwd_apply_bf16_kernel, dim3(grid), dim3(256), 0, st, dout, (long long)lddo, y, (long long)ldy, z,
+  SDM_LAUNCH(gn_bwd_apply_bf16_kernel, dim3(grid), dim3(256), 0, st, dout, (long long)lddo, y, (long long)ldy, z,
                      (long long)ldz, coef, dz, (long long)lddz, rows, HW, C);
   SDM_CHECK_LAUNCH("gn_bwd_apply_bf16");
   return SDM_OK;
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(64 * CSB_W) void col_softmax_bwd_bf16_kernel(const 
 extern "C" int sdm_col_softmax_bwd_bf16(const uint16_t* P, int64_t ldp, const float* dP, int64_t lddp, uint16_t* dS,
                                         int64_t ldds, int batch, int S, float scale, sdm_stream_t s) {
   SDM_CHECK_ARG(P && dP && dS && batch > 0 && S > 0 && ldp >= S && lddp >= S && ldds >= S, "col_softmax_bwd_bf16: bad args");
-  hipLaunchKernelGGL(col_softmax_bwd_bf16_kernel, dim3(cdiv(ldds, 64), batch), dim3(64 * CSB_W), 0, (hipStream_t)s, P, (long long)ldp,
+  SDM_LAUNCH(col_softmax_bwd_bf16_kernel, dim3(cdiv(ldds, 64), batch), dim3(64 * CSB_W), 0, (hipStream_t)s, P, (long long)ldp,
                      dP, (long long)lddp, dS, (long long)ldds, S, scale);
   SDM_CHECK_LAUNCH("col_softmax_bwd_bf16");
   return SDM_OK;
@@ -901,7 +901,7 @@ extern "C" int sdm_silu_bwd_bf16(const uint16_t* dy, const uint16_t* z, uint16_t
   SDM_CHECK_ARG(dy && z && dx && n > 0, "silu_bwd_bf16: bad args");
   size_t grid = (n + 255) / 256;
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(silu_bwd_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)s, dy, z, dx, n);
+  SDM_LAUNCH(silu_bwd_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)s, dy, z, dx, n);
   SDM_CHECK_LAUNCH("silu_bwd_bf16");
   return SDM_OK;
 }
@@ -951,7 +951,7 @@ extern "C" int sdm_colsum_bf16(const uint16_t* x, int64_t ldx, int rows, int C, 
   SDM_CHECK_ARG(x && out && rows > 0 && C > 0, "colsum_bf16: bad args");
   int rpb = (rows + 2047) / 2048;
   if (rpb < 64) rpb = 64;
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)s, x, (long long)ldx, (long long)rows,
+  SDM_LAUNCH(colsum_bf16_kernel, dim3(cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)s, x, (long long)ldx, (long long)rows,
                      C, rpb, out);
   SDM_CHECK_LAUNCH("colsum_bf16");
   return SDM_OK;
@@ -983,7 +983,7 @@ extern "C" int sdm_nchw_to_rows_bf16(const float* x_nchw, uint16_t* out_rows, in
   const long long HW = (long long)H * W, P = HW * images;
   int grid = (int)((P + 255) / 256);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(nchw_to_rows_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, x_nchw, out_rows, C, Cp, HW, P);
+  SDM_LAUNCH(nchw_to_rows_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, x_nchw, out_rows, C, Cp, HW, P);
   SDM_CHECK_LAUNCH("nchw_to_rows_bf16");
   return SDM_OK;
 }

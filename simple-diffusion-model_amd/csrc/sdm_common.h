@@ -22,6 +22,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) {   // round to nearest even (v_
 }
 
 int sdm_set_error(int code, const char* fmt, ...);
+void sdm_plan_taint(const char* why);
 
 #define SDM_CHECK_ARG(cond, ...)                         \
   do {                                                   \
@@ -39,6 +40,7 @@ extern unsigned long long g_sdm_launches;   // kernel launches issued by the lib
 
 #define SDM_MEMSET0(ptr, bytes, st)                                              \
   do {                                                                           \
+    sdm_plan_taint("hipMemsetAsync");                                            \
     if (hipMemsetAsync((ptr), 0, (bytes), (st)) != hipSuccess)                   \
       return sdm_set_error(SDM_ERR_LAUNCH, "hipMemsetAsync failed");             \
   } while (0)
@@ -86,6 +88,31 @@ __device__ __forceinline__ long long sdm_idiv(long long a, long long b) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- launch plan (sdm_plan_begin / sdm_plan_end / sdm_plan_run) -------------------------------------------------------
+// Every kernel launch of the library goes through SDM_LAUNCH.  While a plan is being recorded the launch is ALSO appended
+// to the plan (function, geometry, a copy of the argument values); sdm_plan_run then re-issues the whole sequence from C
+// with one call from the host language -- the ~10 us of Python + ctypes per launch of an eagerly launched step (85
+// launches per N=1 denoise step) become ~2 us of hipLaunchKernel each, and a replayed step costs what an eager one does
+// on the GPU (hipGraph replay measured ~4 % slower than eager launching at N=1, tools/sample_timing.py).
+bool sdm_plan_recording();
+void sdm_plan_push(const void* fn, dim3 grid, dim3 block, size_t lds, void** args, const size_t* sizes, int nargs);
+void sdm_plan_taint(const char* why);          // something ran that the plan cannot replay (a memset, ...)
+
+template <typename T>
+struct sdm_identity { typedef T type; };
+
+template <typename... P>
+static inline void sdm_launch(void (*kern)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t st,
+                              typename sdm_identity<P>::type... a) {
+  void* ptrs[sizeof...(P) > 0 ? sizeof...(P) : 1] = {(void*)&a...};
+  if (sdm_plan_recording()) {
+    const size_t sizes[sizeof...(P) > 0 ? sizeof...(P) : 1] = {sizeof(P)...};
+    sdm_plan_push((const void*)kern, grid, block, lds, ptrs, sizes, (int)sizeof...(P));
+  }
+  (void)hipLaunchKernel((const void*)kern, grid, block, ptrs, lds, st);
+}
+#define SDM_LAUNCH(kern, grid, block, lds, st, ...) sdm_launch(kern, grid, block, lds, st, __VA_ARGS__)
 
 // ---- optional per-launch event timing (sdm_prof_begin / sdm_prof_end) ----
 bool sdm_prof_on();

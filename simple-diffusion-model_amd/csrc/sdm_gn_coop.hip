@@ -229,8 +229,8 @@ extern "C" int sdm_gn_apply_coop(const void* src, int64_t ld_src, int src_raw, f
   a.sums = (double*)state;
   a.ctr = (unsigned*)((char*)state + (size_t)GC_MAX_IMAGES * GC_MAXG * 2 * sizeof(double));
   dim3 grid((unsigned)nsl, images);
-  if (bf16) hipLaunchKernelGGL(gn_apply_coop_kernel<true>, grid, dim3(GC_T), 0, (hipStream_t)s, a);
-  else hipLaunchKernelGGL(gn_apply_coop_kernel<false>, grid, dim3(GC_T), 0, (hipStream_t)s, a);
+  if (bf16) SDM_LAUNCH(gn_apply_coop_kernel<true>, grid, dim3(GC_T), 0, (hipStream_t)s, a);
+  else SDM_LAUNCH(gn_apply_coop_kernel<false>, grid, dim3(GC_T), 0, (hipStream_t)s, a);
   SDM_CHECK_LAUNCH("gn_apply_coop");
   return SDM_OK;
 }

@@ -658,7 +658,7 @@ static int launch_igemm_glds(const IgemmLaunch& L, int ntm, hipStream_t st) {
     sdm_prof_shape(L.d.M, L.d.N, L.d.K, (int)taps, L.splitk, 4.0 * L.d.batch * (in_b + w_b + out_b));
   }
   sdm_prof_pre(st);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, L);
+  SDM_LAUNCH(kern, grid, dim3(256), lds, st, L);
   sdm_prof_post(st, BM == 128 ? (BN == 128 ? 0 : 5) : (BM == 64 ? 1 : 2), 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
   SDM_CHECK_LAUNCH("igemm_glds");
   return SDM_OK;
@@ -730,7 +730,7 @@ static int launch_igemm(const IgemmLaunch& L, int ntm, hipStream_t st) {
     sdm_prof_shape(L.d.M, L.d.N, L.d.K, (int)taps, L.splitk, 4.0 * L.d.batch * (in_b + w_b + out_b));
   }
   sdm_prof_pre(st);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, L);
+  SDM_LAUNCH(kern, grid, dim3(256), lds, st, L);
   sdm_prof_post(st, BM == 128 ? (BN == 128 ? 0 : 5) : (BM == 64 ? 1 : 2), 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
   SDM_CHECK_LAUNCH("igemm");
   return SDM_OK;
@@ -912,7 +912,7 @@ static int launch_skinny(const IgemmLaunch& L, hipStream_t st) {
   }
   sdm_prof_pre(st);
   const size_t dyn = AFF ? (size_t)2 * (L.d.M / (L.d.Ht * L.d.Wt)) * L.d.K * sizeof(float) : 0;
-  hipLaunchKernelGGL((igemm_skinny_kernel<TMB, BKM, AFF>), grid, dim3(256), dyn, st, L);
+  SDM_LAUNCH((igemm_skinny_kernel<TMB, BKM, AFF>), grid, dim3(256), dyn, st, L);
   sdm_prof_post(st, 6, 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
   SDM_CHECK_LAUNCH("igemm_skinny");
   return SDM_OK;
@@ -1160,7 +1160,7 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
       if (grid > 4096) grid = 4096;
       if (grid < 1) grid = 1;
     }
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, st, *d, (long long)out_rows, evec);
+    SDM_LAUNCH(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, st, *d, (long long)out_rows, evec);
     SDM_CHECK_LAUNCH("splitk_epilogue");
   }
   return SDM_OK;
@@ -1528,7 +1528,7 @@ static int launch_wgrad_glds(const WgradLaunch& L, int ntm, hipStream_t st) {
     sdm_prof_shape(L.d.M, L.d.N, (int)((long)L.d.images * L.d.Hk * L.d.Wk), L.d.ntaps, L.splitk, 4.0 * L.d.batch * (g_b + x_b + w_b));
   }
   sdm_prof_pre(st);
-  hipLaunchKernelGGL((wgrad_glds_kernel<BT, WM, WN, NBUF>), grid, dim3(256), lds, st, L);
+  SDM_LAUNCH((wgrad_glds_kernel<BT, WM, WN, NBUF>), grid, dim3(256), lds, st, L);
   sdm_prof_post(st, BT == 128 ? 3 : 4,
                 2.0 * L.d.M * L.d.N * (double)L.d.images * L.d.Hk * L.d.Wk * L.d.ntaps * L.d.batch);
   SDM_CHECK_LAUNCH("wgrad_glds");
@@ -1558,7 +1558,7 @@ static int launch_wgrad(const WgradLaunch& L, int ntm, hipStream_t st) {
     sdm_prof_shape(L.d.M, L.d.N, (int)((long)L.d.images * L.d.Hk * L.d.Wk), L.d.ntaps, L.splitk, 4.0 * L.d.batch * (g_b + x_b + w_b));
   }
   sdm_prof_pre(st);
-  hipLaunchKernelGGL((wgrad_kernel<BT, WM, WN, VEC, AFF>), grid, dim3(256), lds, st, L);
+  SDM_LAUNCH((wgrad_kernel<BT, WM, WN, VEC, AFF>), grid, dim3(256), lds, st, L);
   sdm_prof_post(st, BT == 128 ? 3 : 4,
                 2.0 * L.d.M * L.d.N * (double)L.d.images * L.d.Hk * L.d.Wk * L.d.ntaps * L.d.batch);
   SDM_CHECK_LAUNCH("wgrad");
@@ -1637,7 +1637,7 @@ extern "C" int sdm_wgrad(const sdm_wgrad_desc* d, sdm_stream_t stream) {
       for (int b = 0; b < d->batch; ++b)
         for (int t = 0; t < d->ntaps; ++t) {
           float* p = d->dw + (b / d->bdiv) * d->w_bs0 + (b % d->bdiv) * d->w_bs1 + (long long)d->tap_w[t] * d->w_tap_stride;
-          hipLaunchKernelGGL(zero_rows_kernel, dim3(cdiv((long)d->M * d->N, 1024)), dim3(256), 0, st, p, (long long)d->M,
+          SDM_LAUNCH(zero_rows_kernel, dim3(cdiv((long)d->M * d->N, 1024)), dim3(256), 0, st, p, (long long)d->M,
                              d->N, (long long)d->ldw);
           SDM_CHECK_LAUNCH("zero_rows");
         }

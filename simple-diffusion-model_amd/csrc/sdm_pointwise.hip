@@ -83,7 +83,7 @@ extern "C" int sdm_stem_conv(const float* x, const float* w, const float* bias, 
   SDM_CHECK_ARG(x && w && out && images > 0 && H > 0 && W > 0 && Cout > 0, "stem_conv: bad args");
   SDM_CHECK_ARG(Cin >= 1 && Cin <= EDGE_MAXC, "stem_conv: Cin %d not in [1,%d]", Cin, EDGE_MAXC);
   const long long P = (long long)images * H * W;
-  EDGE_DISPATCH(Cin, hipLaunchKernelGGL(stem_conv_kernel<EC>, dim3(cdiv(P, STEM_PIX)), dim3(256), 0, (hipStream_t)s, x, w,
+  EDGE_DISPATCH(Cin, SDM_LAUNCH(stem_conv_kernel<EC>, dim3(cdiv(P, STEM_PIX)), dim3(256), 0, (hipStream_t)s, x, w,
                                         bias, out, preact, images, H, W, Cout, act));
   SDM_CHECK_LAUNCH("stem_conv");
   return SDM_OK;
@@ -161,9 +161,9 @@ static int stem_conv_wgrad_impl(const float* x, const TG* g, float* dw, float* d
   int ppb = (int)((P + EDGE_WGRAD_BLOCKS - 1) / EDGE_WGRAD_BLOCKS);
   ppb = ((ppb + STEM_PIX - 1) / STEM_PIX) * STEM_PIX;
   const int nb = cdiv(P, ppb);
-  EDGE_DISPATCH(Cin, hipLaunchKernelGGL((stem_wgrad_kernel<EC, TG>), dim3(nb), dim3(256), 0, st, x, g, ws, images, H, W, Cout, ppb));
+  EDGE_DISPATCH(Cin, SDM_LAUNCH((stem_wgrad_kernel<EC, TG>), dim3(nb), dim3(256), 0, st, x, g, ws, images, H, W, Cout, ppb));
   SDM_CHECK_LAUNCH("stem_conv_wgrad");
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv((long)(9 * Cin + 1) * Cout, 256)), dim3(256), 0, st, ws, dw, db, nb,
+  SDM_LAUNCH(stem_wgrad_reduce_kernel, dim3(cdiv((long)(9 * Cin + 1) * Cout, 256)), dim3(256), 0, st, ws, dw, db, nb,
                      Cin, Cout);
   SDM_CHECK_LAUNCH("stem_wgrad_reduce");
   return SDM_OK;
@@ -218,7 +218,7 @@ extern "C" int sdm_head_conv(const float* x, const float* w, const float* bias, 
   const long long P = (long long)images * H * W;
   int grid = (int)((P + 3) / 4);
   if (grid > 8192) grid = 8192;
-  EDGE_DISPATCH(Cout, hipLaunchKernelGGL(head_conv_kernel<EC>, dim3(grid), dim3(256), 0, (hipStream_t)s, x, w, bias, out,
+  EDGE_DISPATCH(Cout, SDM_LAUNCH(head_conv_kernel<EC>, dim3(grid), dim3(256), 0, (hipStream_t)s, x, w, bias, out,
                                          images, Cin, H, W, act));
   SDM_CHECK_LAUNCH("head_conv");
   return SDM_OK;
@@ -266,7 +266,7 @@ static int head_conv_dgrad_impl(const float* dy, const float* w, T* dx, const T*
   const long long P = (long long)images * H * W;
   int grid = (int)((P + 3) / 4);
   if (grid > 8192) grid = 8192;
-  EDGE_DISPATCH(Cout, hipLaunchKernelGGL((head_dgrad_kernel<EC, T>), dim3(grid), dim3(256), 0, (hipStream_t)s, dy, w, dx, z,
+  EDGE_DISPATCH(Cout, SDM_LAUNCH((head_dgrad_kernel<EC, T>), dim3(grid), dim3(256), 0, (hipStream_t)s, dy, w, dx, z,
                                          images, Cin, H, W));
   SDM_CHECK_LAUNCH("head_conv_dgrad");
   return SDM_OK;
@@ -344,10 +344,10 @@ static int head_conv_wgrad_impl(const TX* x, const float* g, float* dw, float* d
   int ppb = (int)((P + EDGE_WGRAD_BLOCKS - 1) / EDGE_WGRAD_BLOCKS);
   if (ppb < 1) ppb = 1;
   const int nb = cdiv(P, ppb);
-  EDGE_DISPATCH(Cout, hipLaunchKernelGGL((head_wgrad_kernel<EC, TX>), dim3(nb), dim3(256), 0, st, x, g, ws, db, images, Cin, H, W,
+  EDGE_DISPATCH(Cout, SDM_LAUNCH((head_wgrad_kernel<EC, TX>), dim3(nb), dim3(256), 0, st, x, g, ws, db, images, Cin, H, W,
                                          ppb));
   SDM_CHECK_LAUNCH("head_conv_wgrad");
-  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(cdiv((long)9 * Cout * Cin, 256)), dim3(256), 0, st, ws, dw, nb, Cin, Cout);
+  SDM_LAUNCH(head_wgrad_reduce_kernel, dim3(cdiv((long)9 * Cout * Cin, 256)), dim3(256), 0, st, ws, dw, nb, Cin, Cout);
   SDM_CHECK_LAUNCH("head_wgrad_reduce");
   return SDM_OK;
 }
@@ -440,7 +440,7 @@ extern "C" int sdm_gn_affine(const float* y, int64_t ldy, int images, int HW, in
   SDM_CHECK_ARG(images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_affine: C %d not divisible by groups %d", C,
                 groups);
   const int vec = ((C / groups) % 4 == 0) && ldy % 4 == 0 && aligned16(y);
-  hipLaunchKernelGGL(gn_affine_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, y, (long long)ldy, HW, C,
+  SDM_LAUNCH(gn_affine_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, y, (long long)ldy, HW, C,
                      groups, eps, gamma, beta, mod, mod_nstride, scale, shift, mean, rstd, vec);
   SDM_CHECK_LAUNCH("gn_affine");
   return SDM_OK;
@@ -497,7 +497,7 @@ extern "C" int sdm_affine_residual(const float* y, int64_t ldy, const float* sca
   long long work = rows * (vec ? C / 4 : C);
   int grid = (int)((work + 255) / 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(affine_residual_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, y, (long long)ldy, scale, shift,
+  SDM_LAUNCH(affine_residual_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, y, (long long)ldy, scale, shift,
                      aff_nstride, x0, (long long)ldx0, x1, (long long)ldx1, csplit, out, (long long)ldo, rows, HW, C, vec);
   SDM_CHECK_LAUNCH("affine_residual");
   return SDM_OK;
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 int sdm_launch_gn_bwd_coef(float* ws, int images, int HW, int C, int groups, const float* gamma, const float* beta,
                            const float* mod, int mod_ns, const float* mean, const float* rstd, float* coef, float* dmod,
                            float* dgamma, float* dbeta, hipStream_t st) {
-  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(images * groups), dim3(64), 0, st, ws, HW, C, groups, gamma, beta, mod, mod_ns,
+  SDM_LAUNCH(gn_bwd_coef_kernel, dim3(images * groups), dim3(64), 0, st, ws, HW, C, groups, gamma, beta, mod, mod_ns,
                      mean, rstd, coef, dmod, dgamma, dbeta);
   SDM_CHECK_LAUNCH("gn_bwd_coef");
   return SDM_OK;
@@ -672,20 +672,20 @@ extern "C" int sdm_gn_adagn_bwd(const float* dout, int64_t lddo, const float* y,
   int rpb = (HW + 63) / 64;
   if (rpb < 8) rpb = 8;
   if (vec && C <= 1024)
-    hipLaunchKernelGGL(gn_bwd_sums_vec_kernel, dim3(cdiv(HW, rpb), images), dim3(256), 0, st, dout, (long long)lddo, y,
+    SDM_LAUNCH(gn_bwd_sums_vec_kernel, dim3(cdiv(HW, rpb), images), dim3(256), 0, st, dout, (long long)lddo, y,
                        (long long)ldy, HW, C, rpb, ws);
   else
-    hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(cdiv(HW, rpb), images), dim3(256), 0, st, dout, (long long)lddo, y,
+    SDM_LAUNCH(gn_bwd_sums_kernel, dim3(cdiv(HW, rpb), images), dim3(256), 0, st, dout, (long long)lddo, y,
                        (long long)ldy, HW, C, rpb, ws);
   SDM_CHECK_LAUNCH("gn_bwd_sums");
-  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(images * groups), dim3(64), 0, st, ws, HW, C, groups, gamma, beta, mod,
+  SDM_LAUNCH(gn_bwd_coef_kernel, dim3(images * groups), dim3(64), 0, st, ws, HW, C, groups, gamma, beta, mod,
                      mod_nstride, mean, rstd, coef, dmod, dgamma, dbeta);
   SDM_CHECK_LAUNCH("gn_bwd_coef");
   const long long rows = (long long)images * HW;
   const long long work = rows * (vec ? C / 4 : C);
   int grid = (int)((work + 255) / 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, dout, (long long)lddo, y, (long long)ldy, z,
+  SDM_LAUNCH(gn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, dout, (long long)lddo, y, (long long)ldy, z,
                      (long long)ldz, coef, dz, (long long)lddz, rows, HW, C, vec ? 1 : 0);
   SDM_CHECK_LAUNCH("gn_bwd_apply");
   return SDM_OK;
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(64 * CS_W) void col_softmax_kernel(float* __restric
 
 extern "C" int sdm_col_softmax(float* scores, int batch, int S, int64_t lds, sdm_stream_t s) {
   SDM_CHECK_ARG(scores && batch > 0 && S > 0 && lds >= S, "col_softmax: bad args");
-  hipLaunchKernelGGL(col_softmax_kernel, dim3(cdiv(S, 64), batch), dim3(64 * CS_W), 0, (hipStream_t)s, scores, S, (long long)lds);
+  SDM_LAUNCH(col_softmax_kernel, dim3(cdiv(S, 64), batch), dim3(64 * CS_W), 0, (hipStream_t)s, scores, S, (long long)lds);
   SDM_CHECK_LAUNCH("col_softmax");
   return SDM_OK;
 }
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(64 * CS_W) void col_softmax_bwd_kernel(const float*
 
 extern "C" int sdm_col_softmax_bwd(const float* p, float* dp, int batch, int S, int64_t lds, float scale, sdm_stream_t s) {
   SDM_CHECK_ARG(p && dp && batch > 0 && S > 0 && lds >= S, "col_softmax_bwd: bad args");
-  hipLaunchKernelGGL(col_softmax_bwd_kernel, dim3(cdiv(S, 64), batch), dim3(64 * CS_W), 0, (hipStream_t)s, p, dp, S,
+  SDM_LAUNCH(col_softmax_bwd_kernel, dim3(cdiv(S, 64), batch), dim3(64 * CS_W), 0, (hipStream_t)s, p, dp, S,
                      (long long)lds, scale);
   SDM_CHECK_LAUNCH("col_softmax_bwd");
   return SDM_OK;
@@ -790,7 +790,7 @@ __global__ void sinusoid_kernel(const int64_t* __restrict__ t, const float* __re
 extern "C" int sdm_sinusoid(const int64_t* t, const float* freq, int n, int D, float* out, sdm_stream_t s) {
   SDM_CHECK_ARG(t && freq && out && n > 0 && D >= 2 && D % 2 == 0, "sinusoid: bad args");
   const int total = n * (D / 2);
-  hipLaunchKernelGGL(sinusoid_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)s, t, freq, n, D, out);
+  SDM_LAUNCH(sinusoid_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)s, t, freq, n, D, out);
   SDM_CHECK_LAUNCH("sinusoid");
   return SDM_OK;
 }
@@ -841,7 +841,7 @@ extern "C" int sdm_linear_small(const float* x, int64_t ldx, const float* w, con
   SDM_CHECK_ARG(add == nullptr || (add_rows == M && ldadd >= O) || (add_rows == 1 && ldadd == 0),
                 "linear_small: addend has %d rows (pitch %lld) for a batch of %d: needs M rows, or 1 row with pitch 0", add_rows,
                 (long long)ldadd, M);
-  hipLaunchKernelGGL(linear_small_kernel, dim3(cdiv(O, 4)), dim3(256), 0, (hipStream_t)s, x, (long long)ldx, w, b, add,
+  SDM_LAUNCH(linear_small_kernel, dim3(cdiv(O, 4)), dim3(256), 0, (hipStream_t)s, x, (long long)ldx, w, b, add,
                      (long long)ldadd, out, (long long)ldo, out_preact, M, K, O, act);
   SDM_CHECK_LAUNCH("linear_small");
   return SDM_OK;
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void linear_multi_kernel(const float* x, long 
 extern "C" int sdm_linear_multi(const float* x, int64_t ldx, int M, int K, const sdm_linear_job* jobs_dev, int njobs,
                                 int maxO, sdm_stream_t s) {
   SDM_CHECK_ARG(x && jobs_dev && M > 0 && K > 0 && njobs > 0 && maxO > 0, "linear_multi: bad args");
-  hipLaunchKernelGGL(linear_multi_kernel, dim3(cdiv(maxO, 4), njobs), dim3(256), 0, (hipStream_t)s, x, (long long)ldx, M, K,
+  SDM_LAUNCH(linear_multi_kernel, dim3(cdiv(maxO, 4), njobs), dim3(256), 0, (hipStream_t)s, x, (long long)ldx, M, K,
                      jobs_dev);
   SDM_CHECK_LAUNCH("linear_multi");
   return SDM_OK;
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256) void linear_multi_bwd_dx_kernel(const sdm_line
 extern "C" int sdm_linear_multi_bwd_dx(const sdm_linear_job* jobs_dev, const int* chunk_job, const int* chunk_o0, int nchunks,
                                        float* dx, int64_t lddx, int M, int K, sdm_stream_t s) {
   SDM_CHECK_ARG(jobs_dev && chunk_job && chunk_o0 && dx && nchunks > 0 && M > 0 && K > 0, "linear_multi_bwd_dx: bad args");
-  hipLaunchKernelGGL(linear_multi_bwd_dx_kernel, dim3(cdiv(K, 256), M, nchunks), dim3(256), 0, (hipStream_t)s, jobs_dev,
+  SDM_LAUNCH(linear_multi_bwd_dx_kernel, dim3(cdiv(K, 256), M, nchunks), dim3(256), 0, (hipStream_t)s, jobs_dev,
                      chunk_job, chunk_o0, dx, (long long)lddx, K);
   SDM_CHECK_LAUNCH("linear_multi_bwd_dx");
   return SDM_OK;
@@ -929,13 +929,13 @@ extern "C" int sdm_linear_small_bwd(const float* dy, int64_t lddy, const float* 
   hipStream_t st = (hipStream_t)s;
   if (dx) {
     (void)dx_accumulate;  // always accumulates (see header)
-    hipLaunchKernelGGL(linear_small_bwd_dx_kernel, dim3(cdiv(K, 256), M, cdiv(O, LSB_OC)), dim3(256), 0, st, dy,
+    SDM_LAUNCH(linear_small_bwd_dx_kernel, dim3(cdiv(K, 256), M, cdiv(O, LSB_OC)), dim3(256), 0, st, dy,
                        (long long)lddy, w, dx, (long long)lddx, M, K, O);
     SDM_CHECK_LAUNCH("linear_small_bwd_dx");
   }
   if (dw) {
     SDM_CHECK_ARG(x != nullptr, "linear_small_bwd: dw needs x");
-    hipLaunchKernelGGL(linear_small_bwd_dw_kernel, dim3(cdiv(K, 256), O), dim3(256), 0, st, dy, (long long)lddy, x,
+    SDM_LAUNCH(linear_small_bwd_dw_kernel, dim3(cdiv(K, 256), O), dim3(256), 0, st, dy, (long long)lddy, x,
                        (long long)ldx, dw, db, M, K, O);
     SDM_CHECK_LAUNCH("linear_small_bwd_dw");
   }
@@ -963,7 +963,7 @@ extern "C" int sdm_colsum(const float* x, int64_t ldx, int rows, int C, float* o
   if (!accumulate) SDM_MEMSET0(out, (size_t)C * sizeof(float), st);
   int rpb = (rows + 511) / 512;
   if (rpb < 4) rpb = 4;
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(rows, rpb)), dim3(256), 0, st, x, (long long)ldx, (long long)rows, C, rpb, out);
+  SDM_LAUNCH(colsum_kernel, dim3(cdiv(rows, rpb)), dim3(256), 0, st, x, (long long)ldx, (long long)rows, C, rpb, out);
   SDM_CHECK_LAUNCH("colsum");
   return SDM_OK;
 }
@@ -988,25 +988,25 @@ __global__ void silu_kernel(const float* x, float* y, size_t n) {
 }
 extern "C" int sdm_silu(const float* x, float* y, size_t n, sdm_stream_t s) {
   SDM_CHECK_ARG(x && y && n > 0, "silu: bad args");
-  hipLaunchKernelGGL(silu_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, y, n);
+  SDM_LAUNCH(silu_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, y, n);
   SDM_CHECK_LAUNCH("silu");
   return SDM_OK;
 }
 extern "C" int sdm_silu_bwd(const float* dy, const float* z, float* dx, size_t n, sdm_stream_t s) {
   SDM_CHECK_ARG(dy && dx && n > 0, "silu_bwd: bad args");
-  hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, dy, z, dx, n);
+  SDM_LAUNCH(silu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, dy, z, dx, n);
   SDM_CHECK_LAUNCH("silu_bwd");
   return SDM_OK;
 }
 extern "C" int sdm_add(const float* a, const float* b, float* y, size_t n, sdm_stream_t s) {
   SDM_CHECK_ARG(a && b && y && n > 0, "add: bad args");
-  hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, a, b, y, n);
+  SDM_LAUNCH(add_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, a, b, y, n);
   SDM_CHECK_LAUNCH("add");
   return SDM_OK;
 }
 extern "C" int sdm_tanh_bwd(const float* dy, const float* y, float* dx, size_t n, sdm_stream_t s) {
   SDM_CHECK_ARG(dy && y && dx && n > 0, "tanh_bwd: bad args");
-  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, dy, y, dx, n);
+  SDM_LAUNCH(tanh_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, dy, y, dx, n);
   SDM_CHECK_LAUNCH("tanh_bwd");
   return SDM_OK;
 }
@@ -1032,7 +1032,7 @@ extern "C" int sdm_mse(const float* a, const float* b, float* loss_out, float* g
   SDM_MEMSET0(loss_out, sizeof(float), st);
   int g = ew_grid(n);
   if (g > 512) g = 512;
-  hipLaunchKernelGGL(mse_kernel, dim3(g), dim3(256), 0, st, a, b, loss_out, grad, n);
+  SDM_LAUNCH(mse_kernel, dim3(g), dim3(256), 0, st, a, b, loss_out, grad, n);
   SDM_CHECK_LAUNCH("mse");
   return SDM_OK;
 }
@@ -1050,7 +1050,7 @@ extern "C" int sdm_q_sample(const float* x0, const float* eps, const float* alph
                             size_t per_image, sdm_stream_t s) {
   SDM_CHECK_ARG(x0 && eps && alpha_bar && xt && images > 0 && per_image > 0, "q_sample: bad args");
   const size_t n = (size_t)images * per_image;
-  hipLaunchKernelGGL(q_sample_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x0, eps, alpha_bar, xt, per_image, n);
+  SDM_LAUNCH(q_sample_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x0, eps, alpha_bar, xt, per_image, n);
   SDM_CHECK_LAUNCH("q_sample");
   return SDM_OK;
 }
@@ -1126,7 +1126,7 @@ extern "C" int sdm_ddpm_update(float* x, const float* eps, const float* z, const
                                unsigned long long seed, const int64_t* rng_step, int* cursor, int nsteps, sdm_stream_t s) {
   SDM_CHECK_ARG(x && eps && coef && n > 0, "ddpm_update: bad args");
   SDM_CHECK_ARG(cursor == nullptr || nsteps > 0, "ddpm_update: cursor without nsteps");
-  hipLaunchKernelGGL(ddpm_update_kernel, dim3(ew_grid(rng_step && !z ? (n + 3) / 4 : n)), dim3(256), 0, (hipStream_t)s, x, eps, z,
+  SDM_LAUNCH(ddpm_update_kernel, dim3(ew_grid(rng_step && !z ? (n + 3) / 4 : n)), dim3(256), 0, (hipStream_t)s, x, eps, z,
                      coef, n, seed, (const long long*)rng_step, cursor, nsteps);
   SDM_CHECK_LAUNCH("ddpm_update");
   return SDM_OK;
@@ -1148,7 +1148,7 @@ extern "C" int sdm_ddim_update(float* x, const float* eps, const float* coef, fl
                                sdm_stream_t s) {
   SDM_CHECK_ARG(x && eps && coef && n > 0, "ddim_update: bad args");
   SDM_CHECK_ARG(cursor == nullptr || nsteps > 0, "ddim_update: cursor without nsteps");
-  hipLaunchKernelGGL(ddim_update_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, eps, coef, x0_out, n, cursor, nsteps);
+  SDM_LAUNCH(ddim_update_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, eps, coef, x0_out, n, cursor, nsteps);
   SDM_CHECK_LAUNCH("ddim_update");
   return SDM_OK;
 }
@@ -1161,7 +1161,7 @@ __global__ void cfg_combine_kernel(const float* e, float* out, float w, size_t n
 }
 extern "C" int sdm_cfg_combine(const float* eps_2n, float* out, float w, size_t n_half, sdm_stream_t s) {
   SDM_CHECK_ARG(eps_2n && out && n_half > 0, "cfg_combine: bad args");
-  hipLaunchKernelGGL(cfg_combine_kernel, dim3(ew_grid(n_half)), dim3(256), 0, (hipStream_t)s, eps_2n, out, w, n_half);
+  SDM_LAUNCH(cfg_combine_kernel, dim3(ew_grid(n_half)), dim3(256), 0, (hipStream_t)s, eps_2n, out, w, n_half);
   SDM_CHECK_LAUNCH("cfg_combine");
   return SDM_OK;
 }
@@ -1184,7 +1184,7 @@ extern "C" int sdm_cold_update(float* x, const float* x0_hat, const float* noise
                                int* cursor, int nsteps, sdm_stream_t s) {
   SDM_CHECK_ARG(x && x0_hat && noise && coef && n > 0, "cold_update: bad args");
   SDM_CHECK_ARG(cursor == nullptr || nsteps > 0, "cold_update: cursor without nsteps");
-  hipLaunchKernelGGL(cold_update_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, x0_hat, noise, coef, n, x0_keep,
+  SDM_LAUNCH(cold_update_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, x0_hat, noise, coef, n, x0_keep,
                      cursor, nsteps);
   SDM_CHECK_LAUNCH("cold_update");
   return SDM_OK;
@@ -1209,7 +1209,7 @@ __global__ void area_resize_kernel(const float* __restrict__ x, float* __restric
 extern "C" int sdm_area_resize(const float* x, float* out, int planes, int Hin, int Win, int Hout, int Wout, sdm_stream_t s) {
   SDM_CHECK_ARG(x && out && planes > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "area_resize: bad args");
   const size_t n = (size_t)planes * Hout * Wout;
-  hipLaunchKernelGGL(area_resize_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, out, (long long)planes, Hin, Win,
+  SDM_LAUNCH(area_resize_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)s, x, out, (long long)planes, Hin, Win,
                      Hout, Wout);
   SDM_CHECK_LAUNCH("area_resize");
   return SDM_OK;
@@ -1246,7 +1246,7 @@ extern "C" int sdm_step_begin(const int* cursor, const int64_t* t_table, const f
                 "step_begin: modulation tables need rows > 0, width %% 4 == 0 and 16-byte aligned buffers");
   long long g = mod_time ? ((long long)rows * (width / 4) + 255) / 256 : 1;
   if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(step_begin_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, cursor, t_table, coef_table, ncoef, nsteps,
+  SDM_LAUNCH(step_begin_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, cursor, t_table, coef_table, ncoef, nsteps,
                      t_cur, coef_cur, mod_time, mod_cond, mods_cur, rows, width);
   SDM_CHECK_LAUNCH("step_begin");
   return SDM_OK;
@@ -1256,7 +1256,7 @@ extern "C" int sdm_step_begin(const int* cursor, const int64_t* t_table, const f
 __global__ void step_advance_kernel(int* cursor, int nsteps) { cursor_advance(cursor, nsteps); }
 extern "C" int sdm_step_advance(int* cursor, int nsteps, sdm_stream_t s) {
   SDM_CHECK_ARG(cursor && nsteps > 0, "step_advance: bad args");
-  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, cursor, nsteps);
+  SDM_LAUNCH(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, cursor, nsteps);
   SDM_CHECK_LAUNCH("step_advance");
   return SDM_OK;
 }
@@ -1291,7 +1291,7 @@ extern "C" int sdm_adam_multi(const sdm_adam_job* jobs_dev, int njobs, int64_t m
   SDM_CHECK_ARG(jobs_dev && njobs > 0 && max_n > 0, "adam_multi: bad args");
   long long g = (max_n + 255) / 256;
   if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(adam_multi_kernel, dim3((int)g, njobs), dim3(256), 0, (hipStream_t)s, jobs_dev, lr, beta1, beta2, eps,
+  SDM_LAUNCH(adam_multi_kernel, dim3((int)g, njobs), dim3(256), 0, (hipStream_t)s, jobs_dev, lr, beta1, beta2, eps,
                      bias_c1, bias_c2, grad_scale, hyper_dev);
   SDM_CHECK_LAUNCH("adam_multi");
   return SDM_OK;
@@ -1327,7 +1327,7 @@ extern "C" int sdm_u8_gather_nchw(const uint8_t* cache_nhwc, const int64_t* idx,
   const long long total = (long long)batch * C * H * W;
   int grid = (int)((total + 255) / 256);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(u8_gather_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, cache_nhwc, idx, flip, lut256, out_nchw, C,
+  SDM_LAUNCH(u8_gather_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, cache_nhwc, idx, flip, lut256, out_nchw, C,
                      H, W, total);
   SDM_CHECK_LAUNCH("u8_gather_nchw");
   return SDM_OK;
@@ -1475,7 +1475,7 @@ extern "C" int sdm_gn_apply_fused_train(const float* src, int64_t ld_src, int sr
                     (x1 == nullptr || (aligned16(x1) && ldx1 % 4 == 0)),
                 "gn_apply_fused: needs channels-per-group %% 4 == 0 and 16-byte aligned rows / tables");
   SDM_CHECK_ARG(act >= 0 && act <= 2, "gn_apply_fused: bad act");
-  hipLaunchKernelGGL(gn_apply_fused_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, (float*)src, (long long)ld_src,
+  SDM_LAUNCH(gn_apply_fused_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, (float*)src, (long long)ld_src,
                      src_raw, alpha, bias, act, HW, C, groups, eps, gamma, beta, mod, mod_nstride, x0, (long long)ldx0, x1,
                      (long long)ldx1, csplit, out, (long long)ldo, z_out, y_out, (long long)ldy, mean, rstd);
   SDM_CHECK_LAUNCH("gn_apply_fused");

@@ -26,6 +26,8 @@ def _use_graph(flag):
     return os.environ.get("SDM_HIPGRAPH", "1") != "0"
 
 
+PLAN = [os.environ.get("SDM_PLAN", "0") == "1"]       # replay the step from the C-side launch plan instead of the hipGraph
+                                                      # (opt-in: measured equal to graph replay, 1.078 vs 1.081 ms at N=1)
 MOD_TABLE = [os.environ.get("SDM_MOD_TABLE", "1") != "0"]       # modulation tables per run (U_Net.modulation_tables)
 MOD_TABLE_MAX_BYTES = 1 << 30
 
@@ -111,15 +113,39 @@ class _StepRunner:
             torch.cuda.current_stream().wait_stream(s)
             self.x.copy_(x0)
             self.cursor.zero_()
+            # SDM_PLAN=1: when the step consists of library launches only (no conditioning image to concatenate, no guidance
+            # batch to build, no injected noise to index: those go through torch kernels), the capture is ALSO recorded as
+            # a C-side launch plan (sdm_plan_*) and the plan is replayed instead of the graph: plain launches issued from
+            # one C call per step.  Measured on MI355X: the same step time as graph replay (1.078 vs 1.081 ms at N=1 fp32;
+            # eager launching 1.030 ms per step once the one-off capture, ~10 ms, is not amortised into it) -- so the
+            # graph stays the default.  The graph stays alive either way: its memory pool owns every buffer the plan uses.
+            planned = PLAN[0] and self.cond_img is None and self.cfg_scale is None and self.noise is None
             self.graph = torch.cuda.CUDAGraph()
+            plan = 0
             with ops.capture_scope() as kept, torch.cuda.graph(self.graph):
-                body()
+                if planned:
+                    lib.call("sdm_plan_begin")
+                try:
+                    body()
+                finally:
+                    if planned:
+                        plan = lib.call("sdm_plan_end")              # 0: something in the step cannot be replayed by a plan
             self._kept = kept             # library buffers the graph points at live exactly as long as the graph
             self.x.copy_(x0)
             self.cursor.zero_()
-            for i in range(self.nsteps):
-                self.graph.replay()
-                on_step(i)
+            try:
+                if plan:
+                    st = ops._stream()
+                    for i in range(self.nsteps):
+                        lib.call("sdm_plan_run", plan, 1, st)
+                        on_step(i)
+                else:
+                    for i in range(self.nsteps):
+                        self.graph.replay()
+                        on_step(i)
+            finally:
+                if plan:
+                    lib.call("sdm_plan_free", plan)
         else:
             for i in range(self.nsteps):
                 body()

@@ -86,6 +86,11 @@ _PROTOS = {
     "sdm_struct_size": (_sz, [_i]),
     "sdm_stream_order": (_i, [fp, fp]),
     "sdm_launch_count": (C.c_ulonglong, []),
+    "sdm_plan_begin": (_i, []),
+    "sdm_plan_end": (_i, []),
+    "sdm_plan_launches": (_i, [_i]),
+    "sdm_plan_run": (_i, [_i, _i, fp]),
+    "sdm_plan_free": (_i, [_i]),
     "sdm_prof_begin": (_i, [_i]),
     "sdm_prof_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sdm_igemm": (_i, [C.POINTER(IgemmDesc), fp]),
