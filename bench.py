@@ -167,12 +167,19 @@ def other_configs(dev, sched, net64):
         xT = torch.randn(n, 3, 64, 64, device=dev, generator=g)
         S.ddpm_sampling(net, sched, xT, 1, 8, device="cuda", log=quiet)                  # warm kernels / scratch sizes
         torch.cuda.synchronize()
-        l0 = lib.launch_count()
+        # library launches of ONE denoise step: eager runs of two and of one step differ by exactly one step (the per-run
+        # setup -- the modulation tables of the whole run -- is in both)
+        counts = []
+        for k in (1, 2):
+            l0 = lib.launch_count()
+            S.ddpm_sampling(net, sched, xT, 1, k, device="cuda", log=quiet, use_graph=False)
+            counts.append(lib.launch_count() - l0)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         S.ddpm_sampling(net, sched, xT, 1, steps, device="cuda", log=quiet)              # includes one graph capture
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / steps
-        return ms, (lib.launch_count() - l0) // 2      # launches of the eager warm-up pass == launches of the captured step
+        return ms, counts[1] - counts[0]
 
     for n in (1, 4):
         for dt, b, peak in ((torch.float32, 4, PEAK_FP32_MFMA_TFLOPS), (torch.bfloat16, 2, PEAK_BF16_MFMA_TFLOPS)):

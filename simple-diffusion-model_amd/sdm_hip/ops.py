@@ -508,8 +508,23 @@ SMALL_ATTN = [os.environ.get("SDM_SMALL_ATTN", "1") != "0"]     # short sequence
 SMALL_ATTN_MAX_S = 256
 
 
-def _small_attn_ok(qkv, S, dk):
-    return SMALL_ATTN[0] and S <= SMALL_ATTN_MAX_S and dk % 16 == 0 and qkv.stride(0) % 8 == 0
+SMALL_ATTN_MAX_WORK = 160 * 1024     # batch * heads * S^2 score elements
+
+
+def _small_attn_ok(qkv, n, heads, S, dk, need_p=True):
+    """The short-sequence cores are built for the launch-bound regime (sampling at batch 1-4, the 4x4 / 8x8 maps of a
+    training step): one or a few workgroups per score tile, operands straight from L2.  Measured against the generic
+    three-launch path (tools/scratch/attn_small_ab.py, profiles/r03_attn_small_ab.txt): they win while batch * heads * S^2
+    stays under ~160k score elements (S = 256: one or two images, 20 vs 36 us; S = 64: up to ~32 images, 13-25 vs 26-30 us;
+    S = 16: any batch) and lose beyond it (S = 256 at 128 images: 1007 vs 229 us), and the form that keeps P (training)
+    only pays at S <= 64."""
+    if not (SMALL_ATTN[0] and S <= SMALL_ATTN_MAX_S and dk % 16 == 0 and qkv.stride(0) % 8 == 0):
+        return False
+    if n * heads * S * S > SMALL_ATTN_MAX_WORK:
+        return False
+    if need_p or not NOGRAD_ATTN[0]:       # the P-keeping form would run
+        return S <= 64
+    return True
 
 
 def attention_core_small(qkv, n, S, heads, dk, Sp, need_p=True):
@@ -539,7 +554,7 @@ def attention_core_fwd(qkv, n, S, heads, dk, keep_p=True):
     dev = qkv.device
     Sp = _pad4(S)
     ld = qkv.stride(0)
-    if _small_attn_ok(qkv, S, dk):
+    if _small_attn_ok(qkv, n, heads, S, dk, need_p=keep_p):
         return attention_core_small(qkv, n, S, heads, dk, Sp, need_p=keep_p)
     P = torch.empty((n * heads, S, Sp), dtype=torch.float32, device=dev)
     d = _base_desc(S, S, dk)
@@ -581,7 +596,7 @@ def attention_core_fwd_bf16(qkv, n, S, heads, dk, keep_p=False):
     dev = qkv.device
     Sp = _pad8(S)
     ld = qkv.stride(0)
-    if _small_attn_ok(qkv, S, dk):
+    if _small_attn_ok(qkv, n, heads, S, dk, need_p=keep_p):
         res, P = attention_core_small(qkv, n, S, heads, dk, Sp, need_p=keep_p)
         return (res, P) if keep_p else res
     B = n * heads

@@ -367,7 +367,7 @@ def test_two_pass_column_softmax_attention(dev, n, S, heads, dk):
     q, k, vv = xr[:, :, :, 0], xr[:, :, :, 1], xr[:, :, :, 2]
     attn = (torch.einsum("nihd,njhd->nijh", q, k) * dk ** -0.5).softmax(dim=1)
     want = torch.einsum("nijh,njhd->nihd", attn, vv).reshape(n * S, heads * dk)
-    assert ops.TWO_PASS_ATTN[0] and not ops._small_attn_ok(x, S, dk)
+    assert ops.TWO_PASS_ATTN[0] and not ops._small_attn_ok(x, n, heads, S, dk)
     res, P = ops.attention_core_fwd_bf16(x, n, S, heads, dk, keep_p=True)
     Pw = attn.permute(0, 3, 1, 2).reshape(n * heads, S, S)
     assert rel(P[:, :, :S].float(), Pw) < 6e-3, rel(P[:, :, :S].float(), Pw)

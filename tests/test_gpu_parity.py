@@ -1048,7 +1048,7 @@ def test_short_sequence_attention_core(dev, n, S, heads, dk, bf16):
     attn = sc.softmax(dim=1)
     want = torch.einsum("nijh,njhd->nihd", attn, vv).reshape(n * S, heads * dk)
     Sp = ops._pad8(S) if bf16 else ops._pad4(S)
-    assert ops._small_attn_ok(x, S, dk)
+    assert ops._small_attn_ok(x, 1, 1, 16, dk)
     res, P = ops.attention_core_small(x, n, S, heads, dk, Sp)
     tolP, tolR = (8e-3, 8e-3) if bf16 else (2e-5, 2e-5)
     Pw = attn.permute(0, 3, 1, 2).reshape(n * heads, S, S)
