@@ -264,3 +264,58 @@ def test_dataset_record_order_is_rank_consistent_under_data_parallelism(tmp_path
     random.seed(8)
     b = [r[0] for r in ConditionalImgDataset(str(tmp_path / "dbc.json")).dataset]
     assert sorted(a) == sorted(b) and a != b
+
+
+def test_argument_validation_under_asan_ubsan(tmp_path):
+    """SURVEY §5 "race detection / sanitizers": the entry points' argument-validation and bookkeeping paths (no GPU call is
+    reached) under a host AddressSanitizer + UndefinedBehaviorSanitizer build of the light translation units
+    (`make -C csrc asan`; device code is not instrumented).  Runs in a child process with the sanitizer runtime preloaded; any
+    report fails the child (halt_on_error)."""
+    import subprocess
+    import glob
+    csrc = os.path.join(ROOT, "simple-diffusion-model_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "asan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    so = os.path.join(ROOT, "simple-diffusion-model_amd", "sdm_hip", "libsdm_hip_asan.so")
+    rt = glob.glob("/opt/rocm*/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    if not rt:
+        pytest.skip("no ASan runtime in this image")
+    child = r"""
+import ctypes as C, sys
+L = C.CDLL(sys.argv[1])
+L.sdm_last_error.restype = C.c_char_p
+p = C.c_void_p
+def call(name, *a):
+    rc = getattr(L, name)(*a)
+    return rc, L.sdm_last_error().decode()
+bad = 0x1000
+checks = [
+  ("sdm_col_softmax", (p(None), 0, 0, C.c_int64(0), p(None)), "col_softmax"),
+  ("sdm_linear_small", (p(bad), C.c_int64(32), p(bad), p(bad), p(bad), C.c_int64(32), 2, p(bad), C.c_int64(32), p(None), 4, 32, 32, 0, p(None)), "addend has 2 rows"),
+  ("sdm_step_begin", (p(None), p(None), p(None), 3, 5, p(None), p(None), p(None), p(None), p(None), 0, 0, p(None)), "step_begin"),
+  ("sdm_step_begin", (p(bad), p(bad), p(bad), 3, 5, p(bad), p(bad), p(bad), p(None), p(bad), 1, 6, p(None)), "width"),
+  ("sdm_ddpm_update", (p(None), p(None), p(None), p(None), C.c_size_t(0), C.c_ulonglong(1), p(None), p(None), 0, p(None)), "ddpm_update"),
+  ("sdm_ddim_update", (p(bad), p(bad), p(bad), p(None), C.c_size_t(4), p(bad), 0, p(None)), "cursor without nsteps"),
+  ("sdm_attn_scores_small", (p(bad), C.c_int64(48), 1, 300, 1, 16, C.c_float(1.0), p(bad), C.c_int64(300), 0, p(None)), "at most 256"),
+  ("sdm_attn_scores_small", (p(bad), C.c_int64(48), 1, 16, 1, 12, C.c_float(1.0), p(bad), C.c_int64(16), 0, p(None)), "multiple of 16"),
+  ("sdm_attn_small_nograd", (p(bad), C.c_int64(48), 1, 16, 1, 16, C.c_float(1.0), p(bad), C.c_int64(16), 0, p(None), C.c_size_t(0), p(None)), "attn_small_nograd"),
+  ("sdm_gn_apply_coop", (p(bad), C.c_int64(128), 0, C.c_float(1.0), p(None), 0, 1, 4096, 128, 32, C.c_float(1e-5), p(bad), p(bad), p(None), 0, p(None), C.c_int64(0), p(None), C.c_int64(0), 0, p(bad), C.c_int64(128), 0, p(None), C.c_size_t(0), p(None)), "state buffer"),
+  ("sdm_plan_end", (), "no plan is being recorded"),
+  ("sdm_plan_run", (7, 1, p(None)), "bad handle"),
+  ("sdm_prof_begin", (0,), "capacity"),
+]
+for name, args, frag in checks:
+    rc, err = call(name, *args)
+    assert rc < 0 and frag in err, (name, rc, err)
+assert L.sdm_plan_begin() == 0 and L.sdm_plan_begin() < 0            # second recording refused
+assert L.sdm_plan_end() == 0 and "no launches" in L.sdm_last_error().decode()
+L.sdm_struct_size.restype = C.c_size_t
+assert L.sdm_struct_size(0) > 400 and L.sdm_struct_size(99) == 0
+L.sdm_gn_apply_coop_state_bytes.restype = C.c_size_t
+assert L.sdm_gn_apply_coop_state_bytes() > 0 and L.sdm_version() >= 300
+print("asan-ok")
+"""
+    env = dict(os.environ, LD_PRELOAD=rt[0], ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-c", child, so], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "asan-ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
