@@ -241,6 +241,10 @@ int sdm_stem_conv_wgrad(const float* x_nchw, const float* g_nhwc, float* dw_tap,
                         int images, int Cin, int H, int W, int Cout, sdm_stream_t s);
 int sdm_head_conv_wgrad(const float* x_nhwc, const float* g_nchw, float* dw_tap, float* dbias, float* ws,
                         int images, int Cin, int H, int W, int Cout, sdm_stream_t s);
+/* NCHW fp32 -> NHWC fp32 rows [images*H*W][Cp] (channels [C, Cp) zero): the image side of the edge convs as pixel rows, so
+ * that their weight gradients run on sdm_wgrad (matrix cores) -- 3x / 1.5x faster than the two entry points above at 64x64
+ * batch 4, which remain for callers that have no row buffer. */
+int sdm_nchw_to_rows(const float* x_nchw, float* out_rows, int images, int C, int H, int W, int Cp, sdm_stream_t s);
 
 /* GroupNorm(32) statistics of y [images][HW][C] folded with the AdaGN modulation into the
  * per-(image,channel) affine that consumers apply on load (custom_layers.py:35-45, quirk: shift==scale):

@@ -1481,3 +1481,26 @@ extern "C" int sdm_gn_apply_fused_train(const float* src, int64_t ld_src, int sr
   SDM_CHECK_LAUNCH("gn_apply_fused");
   return SDM_OK;
 }
+
+// --------------------------------------------------------------------------------------------
+// NCHW fp32 [images][C][H][W] -> NHWC fp32 rows [images*H*W][Cp] (channels [C, Cp) zero): the 3- / 6-channel side of the
+// edge convs as pixel rows, so that their WEIGHT gradients run on the matrix-core kernel (sdm_wgrad) like every other
+// conv's (U_Net.py:55-60,121-128 backward).  Measured at 64x64 batch 4 (tools/scratch/edge_wgrad_ab.py): head conv
+// 155.6 -> 49.5 us, stem conv 77.7 -> 52.4 us against the one-wave-per-pixel kernels + slab reduction.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int C, long long HW,
+                                                           long long P, int Cp) {
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long long)gridDim.x * 256) {
+    const long long n = sdm_idiv(p, HW), rem = p - n * HW;
+    for (int c = 0; c < Cp; ++c) out[p * Cp + c] = c < C ? x[(n * C + c) * HW + rem] : 0.f;
+  }
+}
+extern "C" int sdm_nchw_to_rows(const float* x_nchw, float* out_rows, int images, int C, int H, int W, int Cp, sdm_stream_t s) {
+  SDM_CHECK_ARG(x_nchw && out_rows && images > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, "nchw_to_rows: bad args");
+  const long long HW = (long long)H * W, P = HW * images;
+  int grid = (int)((P + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  SDM_LAUNCH(nchw_to_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, x_nchw, out_rows, C, HW, P, Cp);
+  SDM_CHECK_LAUNCH("nchw_to_rows");
+  return SDM_OK;
+}

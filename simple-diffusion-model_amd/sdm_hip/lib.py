@@ -102,6 +102,7 @@ _PROTOS = {
     "sdm_edge_wgrad_workspace_bytes": (_sz, [_i, _i]),
     "sdm_stem_conv_wgrad": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "sdm_head_conv_wgrad": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "sdm_nchw_to_rows": (_i, [fp, fp, _i, _i, _i, _i, _i, fp]),
     "sdm_gn_affine": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, fp, fp, fp, fp]),
     "sdm_gn_apply_fused": (_i, [fp, _i64, _i, _f, fp, _i, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, fp]),
     "sdm_gn_apply_coop_state_bytes": (_sz, []),

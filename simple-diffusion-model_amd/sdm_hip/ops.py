@@ -288,6 +288,15 @@ def nchw_to_rows_bf16(x, cp=8):
     return out
 
 
+def nchw_to_rows(x, cp=4):
+    """NCHW fp32 [n, c, h, w] -> NHWC fp32 rows [n*h*w, cp] (channels [c, cp) zero): the image side of the edge convs as
+    pixel rows for the matrix-core weight-gradient kernel."""
+    n, c, h, w = x.shape
+    out = torch.empty((n * h * w, cp), dtype=torch.float32, device=x.device)
+    lib.call("sdm_nchw_to_rows", _p(x), _p(out), n, c, h, w, cp, _stream())
+    return out
+
+
 def _base_desc(M, N, K):
     d = IgemmDesc()
     d.M, d.N, d.K, d.batch, d.bdiv = M, N, K, 1, 1
