@@ -280,6 +280,18 @@ int sdm_gn_apply_coop(const void* src, int64_t ld_src, int src_raw, float alpha,
                       const void* x0, int64_t ldx0, const void* x1, int64_t ldx1, int csplit, void* out, int64_t ldo, int bf16,
                       void* state, size_t state_bytes, sdm_stream_t s);
 
+/* sdm_gn_adagn_bwd (or its bf16-rows form, bf16 = 1) in ONE launch for maps that fit 256 slabs of 4096 channel quads: the
+ * slab's dout / y / z stay in registers, the per-group pair the apply needs crosses once (fp64 atomics + arrival counter,
+ * the forward kernel's `state`), the per-channel sums go to `ws` ([images][C][2] fp32, zero on entry, zero on return) with
+ * fire-and-forget atomics and the LAST slab of an image to leave turns them into dmod / dgamma / dbeta.  An image that
+ * fits one slab uses no atomics at all.  Same results as sdm_gn_adagn_bwd up to the summation order of the group pair
+ * (fp64 here).  Returns SDM_NOT_APPLICABLE (nothing launched) outside the envelope: C a power of two in 128..1024,
+ * channels per group a power of two in 4..64, images * slabs <= 256. */
+int sdm_gn_bwd_coop(const void* dout, int64_t lddo, const void* y, int64_t ldy, const void* z, int64_t ldz, int images, int HW,
+                    int C, int groups, const float* gamma, const float* beta, const float* mod, int mod_nstride,
+                    const float* mean, const float* rstd, void* dz, int64_t lddz, float* dmod, float* dgamma, float* dbeta,
+                    float* ws, int bf16, void* state, size_t state_bytes, sdm_stream_t s);
+
 /* The same pass inside a TRAINING step (small layers, where the step is a chain of dependent launches): additionally
  * leaves what the block's backward reads -- mean / rstd [images][groups] (both or neither) and, for raw sums, the conv's own
  * finished rows y_out (activated, pitch ldy) and z_out (pre-activation, optional; same pitch).  sdm_igemm(defer_epilogue)

@@ -234,3 +234,266 @@ extern "C" int sdm_gn_apply_coop(const void* src, int64_t ld_src, int src_raw, f
   SDM_CHECK_LAUNCH("gn_apply_coop");
   return SDM_OK;
 }
+
+// --------------------------------------------------------------------------------------------
+// AdaGN backward in ONE launch (sdm_gn_adagn_bwd runs three: channel sums, coefficients, apply).  OPT-IN experiment
+// (ops.GN_COOP_BWD / SDM_GN_COOP_BWD=1): correct, but inside the fp32 training step it loses to the three launches -- the
+// slabs must all be resident before any can finish and the weight-gradient stream keeps the CUs full (64x64 maps: 118 us
+// against 69 us; small maps tie at ~16 us), profiles/r03_gn_bwd_coop.txt.  Same slab ownership and the same single
+// exchange as the forward kernel above:
+//   a lane keeps its dout / y / z elements (all of one channel quad) in registers;
+//   per-channel partials (sum dout, sum dout*y) meet in LDS; thread t < C sends channel t's pair to ws[image][t][2] with
+//   fp32 atomics (nobody waits for those) and the lanes of a group reduce  P = sum_c s_c gamma_c S1_c,  Q = sum_c s_c gamma_c S2_c
+//   into TWO fp64 atomics per group: that pair is all the apply needs (k1, k2 of sdm_gn_adagn_bwd's coefficient pass);
+//   arrival / poll / read-back as above; apply from registers;
+//   the LAST slab of an image to depart turns the finished channel sums into dmod / dgamma / dbeta (what the
+//   coefficient pass emitted) and leaves ws, the group sums and the counters zero.
+// An image that fits one slab skips the exchange altogether (no atomics, no polling).
+// --------------------------------------------------------------------------------------------
+struct GnBwdCoopArgs {
+  const void* dout; long long lddo; const void* y; long long ldy; const void* z; long long ldz;
+  int HW, C, groups;
+  const float* gamma; const float* beta; const float* mod; int mod_ns;
+  const float* mean; const float* rstd;
+  void* dz; long long lddz;
+  float* dmod; float* dgamma; float* dbeta;
+  float* ws;                     // [images][C][2], zero between launches
+  int slab_rows, lc4, lq4;
+  double* sums; unsigned* ctr;   // the forward kernel's exchange state
+};
+
+template <bool BF>
+__device__ __forceinline__ f32x4 gc_load4(const void* p, long long idx) {
+  if (BF) {
+    const u16x4 u = *(const u16x4*)((const bf16_t*)p + idx);
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = bf2f(u[i]);
+    return v;
+  }
+  return *(const f32x4*)((const float*)p + idx);
+}
+
+template <bool BF, int T>
+__global__ __launch_bounds__(T) void gn_bwd_coop_kernel(const GnBwdCoopArgs a) {
+  __shared__ float lsC[2][GC_T];         // this slab's per-channel partials (C <= GC_T = 1024)
+  __shared__ double lg[2][GC_MAXG];      // single-slab images: the group pair without the trip through memory
+  __shared__ float st[2][GC_MAXG];       // k1, k2 per group
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int n = blockIdx.y, nsl = gridDim.x;
+  const int C4 = a.C >> 2;
+  const int r0 = blockIdx.x * a.slab_rows;
+  const int nrows = min(a.slab_rows, a.HW - r0);
+  const long long row0 = (long long)n * a.HW + r0;
+  const int quad = tid & (C4 - 1);
+  const int c = quad * 4, g = quad >> a.lq4;
+  const int rstep = T >> a.lc4, rfirst = tid >> a.lc4;
+  const int cpg = a.C / a.groups;
+  for (int i = tid; i < 2 * GC_T; i += T) (&lsC[0][0])[i] = 0.f;
+  __syncthreads();
+
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 d[GC_MAXV], yv[GC_MAXV], zv[GC_MAXV];
+  f32x4 s1 = zero4, s2 = zero4;
+#pragma unroll
+  for (int k = 0; k < GC_MAXV; ++k) {
+    const int r = rfirst + k * rstep;
+    d[k] = zero4; yv[k] = zero4; zv[k] = zero4;
+    if (r < nrows) {
+      d[k] = gc_load4<BF>(a.dout, (row0 + r) * a.lddo + c);
+      yv[k] = gc_load4<BF>(a.y, (row0 + r) * a.ldy + c);
+      if (a.z) zv[k] = gc_load4<BF>(a.z, (row0 + r) * a.ldz + c);
+      s1 += d[k];
+      s2 += d[k] * yv[k];
+    }
+  }
+  // lanes of a wave that hold the same quad (C4 < 64): fold before touching LDS
+  for (int o = C4; o < 64; o <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s1[i] += __shfl_xor(s1[i], o, 64);
+      s2[i] += __shfl_xor(s2[i], o, 64);
+    }
+  }
+  if (C4 >= 64 || lane < C4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      atomicAdd(&lsC[0][c + i], s1[i]);
+      atomicAdd(&lsC[1][c + i], s2[i]);
+    }
+  }
+  __syncthreads();
+  double* gs = a.sums + (long long)n * GC_MAXG * 2;
+  unsigned* ctr = a.ctr + n * 2;
+  float* wsn = a.ws + (long long)n * a.C * 2;
+  for (int t = tid; t < a.C; t += T) {   // whole waves: C is a multiple of 128 (host check), so the shuffles below are uniform
+    const float S1 = lsC[0][t], S2 = lsC[1][t];
+    if (nsl > 1) {
+      atomicAdd(wsn + t * 2, S1);
+      atomicAdd(wsn + t * 2 + 1, S2);
+    }
+    const float sg = (a.mod ? a.mod[(long long)n * a.mod_ns + t] : 1.f) * a.gamma[t];
+    double p = (double)sg * (double)S1, q = (double)sg * (double)S2;
+    for (int o = 1; o < cpg; o <<= 1) {
+      p += __shfl_xor(p, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
+    if ((t & (cpg - 1)) == 0) {
+      const int gg = t / cpg;
+      if (nsl > 1) {
+        atomicAdd(gs + gg * 2, p);
+        atomicAdd(gs + gg * 2 + 1, q);
+      } else {
+        lg[0][gg] = p;
+        lg[1][gg] = q;
+      }
+    }
+  }
+  if (nsl > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (nsl > 1) {
+    if (tid == 0) {
+      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nsl) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+  }
+  if (tid < a.groups) {
+    double P, Q;
+    if (nsl > 1) {
+      P = __hip_atomic_load(gs + tid * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      Q = __hip_atomic_load(gs + tid * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      P = lg[0][tid];
+      Q = lg[1][tid];
+    }
+    const double mu = a.mean[n * a.groups + tid], rs = a.rstd[n * a.groups + tid];
+    const double cnt = (double)a.HW * (double)cpg;
+    const double A = P / cnt, B = rs * (Q - mu * P) / cnt;
+    st[0][tid] = (float)(-rs * rs * B);
+    st[1][tid] = (float)(-rs * A + mu * rs * rs * B);
+  }
+  __syncthreads();
+  {
+    const float rs = a.rstd[n * a.groups + g];
+    const float k1 = st[0][g], k2 = st[1][g];
+    const f32x4 ga = *(const f32x4*)(a.gamma + c);
+    f32x4 k0;
+    if (a.mod) {
+      const f32x4 sm = *(const f32x4*)(a.mod + (long long)n * a.mod_ns + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) k0[i] = rs * sm[i] * ga[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) k0[i] = rs * ga[i];
+    }
+#pragma unroll
+    for (int k = 0; k < GC_MAXV; ++k) {
+      const int r = rfirst + k * rstep;
+      if (r >= nrows) continue;
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = k0[i] * d[k][i] + k1 * yv[k][i] + k2;
+        if (a.z) v[i] *= sdm_dsilu(zv[k][i]);
+      }
+      const long long idx = (row0 + r) * a.lddz + c;
+      if (BF) {
+        u16x4 u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = f2bf(v[i]);
+        *(u16x4*)((bf16_t*)a.dz + idx) = u;
+      } else {
+        *(f32x4*)((float*)a.dz + idx) = v;
+      }
+    }
+  }
+  // departure; the last slab of the image finishes the per-channel outputs and resets the state
+  __syncthreads();
+  if (nsl > 1) {
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == (unsigned)nsl - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+  }
+  for (int t = tid; t < a.C; t += T) {
+    float S1, S2;
+    if (nsl > 1) {
+      S1 = __hip_atomic_load(wsn + t * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      S2 = __hip_atomic_load(wsn + t * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(wsn + t * 2, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(wsn + t * 2 + 1, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      S1 = lsC[0][t];
+      S2 = lsC[1][t];
+    }
+    const int gg = t / cpg;
+    const float mu = a.mean[n * a.groups + gg], rs = a.rstd[n * a.groups + gg];
+    const float sm = a.mod ? a.mod[(long long)n * a.mod_ns + t] : 1.f;
+    const float ga = a.gamma[t], be = a.beta[t];
+    const float xh = rs * (S2 - mu * S1);
+    if (a.dmod) a.dmod[(long long)n * a.C + t] = ga * xh + (a.mod ? (be + 1.f) : be) * S1;
+    if (a.dgamma) atomicAdd(&a.dgamma[t], sm * xh);
+    if (a.dbeta) atomicAdd(&a.dbeta[t], sm * S1);
+  }
+  if (nsl > 1 && tid < a.groups * 2) __hip_atomic_store(gs + tid, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (nsl > 1 && tid == 0) {
+    __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+extern "C" int sdm_gn_bwd_coop(const void* dout, int64_t lddo, const void* y, int64_t ldy, const void* z, int64_t ldz, int images,
+                               int HW, int C, int groups, const float* gamma, const float* beta, const float* mod,
+                               int mod_nstride, const float* mean, const float* rstd, void* dz, int64_t lddz, float* dmod,
+                               float* dgamma, float* dbeta, float* ws, int bf16, void* state, size_t state_bytes,
+                               sdm_stream_t s) {
+  SDM_CHECK_ARG(dout && y && gamma && beta && mean && rstd && dz && ws, "gn_bwd_coop: null pointer");
+  SDM_CHECK_ARG(images > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_bwd_coop: bad dims");
+  SDM_CHECK_ARG(state && state_bytes >= sdm_gn_apply_coop_state_bytes() && aligned16(state), "gn_bwd_coop: state buffer");
+  const int cpg = C / groups;
+  const int lc4 = ilog2x(C / 4), lq4 = cpg % 4 == 0 ? ilog2x(cpg / 4) : -1;
+  // envelope (else the caller runs sdm_gn_adagn_bwd): power-of-two quads per row and per group, a channel per thread in the
+  // per-channel steps (C <= 1024, whole 128-lane pairs of waves), a group inside one wave, at most 256 workgroups in all
+  if (C % 128 != 0 || lc4 < 0 || lq4 < 0 || C > GC_T || cpg > 64 || groups > GC_MAXG || images > GC_MAX_IMAGES) return SDM_NOT_APPLICABLE;
+  // workgroup size: 256 threads by default -- a 1024-thread workgroup (4 waves x 80 registers per SIMD) does not fit on a CU
+  // beside a weight-gradient workgroup of the side stream and waits for whole CUs to drain (measured: the fp32 step got
+  // 0.15 ms SLOWER with it); SDM_GN_BWD_T=1024 selects the large form
+  static const char* ts = getenv("SDM_GN_BWD_T");
+  const int T = (ts && atoi(ts) == 1024) ? 1024 : 256;
+  if (C / 4 > T) return SDM_NOT_APPLICABLE;
+  const long long quads = (long long)HW * (C / 4);
+  long long nsl = 1;
+  while (nsl * T * GC_MAXV < quads) nsl <<= 1;
+  if (nsl * images > (T == 1024 ? 256 : 1024)) return SDM_NOT_APPLICABLE;     // all resident at once: 4 small workgroups per CU at most
+  const int slab_rows = (int)((HW + nsl - 1) / nsl);
+  if ((long long)slab_rows * (C / 4) > (long long)T * GC_MAXV) return SDM_NOT_APPLICABLE;
+  const size_t esz = bf16 ? 2 : 4;
+  auto al = [](const void* q, size_t a_) { return (((uintptr_t)q) & (a_ - 1)) == 0; };
+  SDM_CHECK_ARG(al(dout, 4 * esz) && lddo % 4 == 0 && al(y, 4 * esz) && ldy % 4 == 0 && al(dz, 4 * esz) && lddz % 4 == 0 &&
+                    (z == nullptr || (al(z, 4 * esz) && ldz % 4 == 0)) && aligned16(gamma) && aligned16(beta) &&
+                    (mod == nullptr || (aligned16(mod) && mod_nstride % 4 == 0)),
+                "gn_bwd_coop: rows and tables must be aligned to four elements");
+  GnBwdCoopArgs a;
+  a.dout = dout; a.lddo = lddo; a.y = y; a.ldy = ldy; a.z = z; a.ldz = ldz;
+  a.HW = HW; a.C = C; a.groups = groups;
+  a.gamma = gamma; a.beta = beta; a.mod = mod; a.mod_ns = mod_nstride;
+  a.mean = mean; a.rstd = rstd;
+  a.dz = dz; a.lddz = lddz; a.dmod = dmod; a.dgamma = dgamma; a.dbeta = dbeta; a.ws = ws;
+  a.slab_rows = slab_rows; a.lc4 = lc4; a.lq4 = lq4;
+  a.sums = (double*)state;
+  a.ctr = (unsigned*)((char*)state + (size_t)GC_MAX_IMAGES * GC_MAXG * 2 * sizeof(double));
+  dim3 grid((unsigned)nsl, images);
+  if (T == 1024) {
+    if (bf16) SDM_LAUNCH((gn_bwd_coop_kernel<true, 1024>), grid, dim3(1024), 0, (hipStream_t)s, a);
+    else SDM_LAUNCH((gn_bwd_coop_kernel<false, 1024>), grid, dim3(1024), 0, (hipStream_t)s, a);
+  } else {
+    if (bf16) SDM_LAUNCH((gn_bwd_coop_kernel<true, 256>), grid, dim3(256), 0, (hipStream_t)s, a);
+    else SDM_LAUNCH((gn_bwd_coop_kernel<false, 256>), grid, dim3(256), 0, (hipStream_t)s, a);
+  }
+  SDM_CHECK_LAUNCH("gn_bwd_coop");
+  return SDM_OK;
+}

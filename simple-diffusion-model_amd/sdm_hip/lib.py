@@ -108,6 +108,8 @@ _PROTOS = {
     "sdm_gn_apply_coop_state_bytes": (_sz, []),
     "sdm_gn_apply_coop": (_i, [fp, _i64, _i, _f, fp, _i, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, _i, fp, _sz,
                               fp]),
+    "sdm_gn_bwd_coop": (_i, [fp, _i64, fp, _i64, fp, _i64, _i, _i, _i, _i, fp, fp, fp, _i, fp, fp, fp, _i64, fp, fp, fp, fp, _i, fp,
+                            _sz, fp]),
     "sdm_gn_apply_fused_train": (_i, [fp, _i64, _i, _f, fp, _i, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64,
                                       fp, fp, _i64, fp, fp, fp]),
     "sdm_affine_residual": (_i, [fp, _i64, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, _i, _i, _i, fp]),

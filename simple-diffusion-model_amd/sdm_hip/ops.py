@@ -883,6 +883,10 @@ def gn_affine(y, gamma, beta, mod, groups=32, eps=1e-5, want_stats=True):
 
 
 GN_COOP = [os.environ.get("SDM_GN_COOP", "1") != "0"]
+# one-launch AdaGN backward (sdm_gn_bwd_coop): OFF by default.  Measured in the fp32 training step it is SLOWER than the three
+# small kernels (7.2 -> 7.45 ms): its slabs must all be resident before any can finish, and the weight-gradient stream
+# keeps the CUs full, so the big maps wait 118 us where the three kernels take 69; the small maps tie (17 vs 15 us).
+GN_COOP_BWD = [os.environ.get("SDM_GN_COOP_BWD", "0") == "1"]
 _GN_COOP_STATE = {}
 
 
@@ -972,8 +976,16 @@ def gn_adagn_bwd(dout, y, z, n, hw, gamma, beta, mod, mean, rstd, dgamma, dbeta,
     if dmod is None and mod is not None:
         dmod = torch.empty((n, C_), dtype=torch.float32, device=dev)
     ws = GNWS.get(n * C_ * 2 * 4, dev)         # persistent, zero-filled; the kernels leave it zero
-    coef = torch.empty((n * 3 * C_,), dtype=torch.float32, device=dev)
     mns = 0 if (mod is None or mod.shape[0] == 1) else mod.stride(0)
+    if GN_COOP_BWD[0]:
+        # one launch instead of three (sdm_gn_coop.hip); declines maps that do not fit its register-resident slabs
+        st = _gn_coop_state(dev)
+        rc = lib.call("sdm_gn_bwd_coop", _p(dout), dout.stride(0), _p(y), y.stride(0), _p(z), z.stride(0) if z is not None else 0,
+                      n, hw, C_, groups, _p(gamma), _p(beta), _p(mod), mns, _p(mean), _p(rstd), _p(dz), dz.stride(0), _p(dmod),
+                      _p(dgamma), _p(dbeta), _p(ws), int(y.dtype == BF16), _p(st), st.numel(), _stream())
+        if rc != lib.NOT_APPLICABLE:
+            return dz, dmod
+    coef = torch.empty((n * 3 * C_,), dtype=torch.float32, device=dev)
     lib.call("sdm_gn_adagn_bwd_bf16" if y.dtype == BF16 else "sdm_gn_adagn_bwd", _p(dout), dout.stride(0), _p(y), y.stride(0), _p(z), z.stride(0) if z is not None else 0,
              n, hw, C_, groups, _p(gamma), _p(beta), _p(mod), mns, _p(mean), _p(rstd), _p(dz), dz.stride(0), _p(dmod),
              _p(dgamma), _p(dbeta), _p(ws), _p(coef), _stream())

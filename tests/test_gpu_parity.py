@@ -1122,6 +1122,77 @@ def test_cooperative_groupnorm_tail_repeats_and_matches_the_per_group_kernel(dev
         assert int(st.to(torch.int32).abs().sum()) == 0                   # sums and counters back to zero
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_cooperative_groupnorm_backward_matches_the_three_kernel_path_and_autograd(dev, bf16):
+    """sdm_gn_bwd_coop (one launch: channel sums, group pair exchanged once, apply from registers, last slab emits dmod /
+    dgamma / dbeta) against sdm_gn_adagn_bwd on the same inputs and against torch autograd of s*GN(y)+s -> SiLU', with and
+    without modulation / pre-activation, for one-slab images (no exchange) and many-slab images; 200 launches back to back
+    leave the exchange state and the channel-sum scratch zero.  (The kernel is opt-in: slower than the three launches
+    inside the training step, see ops.GN_COOP_BWD.)"""
+    from sdm_hip import lib, ops
+    g = torch.Generator().manual_seed(15)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    for (n, h, w, c) in ((4, 4, 4, 1024), (4, 8, 8, 512), (2, 16, 16, 512), (4, 32, 32, 256), (4, 64, 64, 128), (3, 24, 24, 128)):
+        rows, hw = n * h * w, h * w
+        y = (torch.randn(rows, c, generator=g) * 1.5 + 0.3).to(dev).to(dt)
+        z = torch.randn(rows, c, generator=g).to(dev).to(dt)
+        dout = torch.randn(rows, c, generator=g).to(dev).to(dt)
+        gamma, beta = (torch.rand(c, generator=g) + 0.5).to(dev), torch.randn(c, generator=g).to(dev)
+        for with_mod, with_z in ((True, True), (False, False)):
+            mod = torch.randn(n, c, generator=g).to(dev) if with_mod else None
+            _, _, mean, rstd = ops.gn_affine(ops.Act(y, n, h, w), gamma, beta, mod, want_stats=True)
+            res = {}
+            for coop in (True, False):
+                was, ops.GN_COOP_BWD[0] = ops.GN_COOP_BWD[0], coop
+                try:
+                    dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+                    l0 = lib.launch_count()
+                    dz, dm = ops.gn_adagn_bwd(dout, y, z if with_z else None, n, hw, gamma, beta, mod, mean, rstd, dg, db)
+                    res[coop] = (dz.float(), dm, dg, db, lib.launch_count() - l0)
+                finally:
+                    ops.GN_COOP_BWD[0] = was
+            assert res[True][4] == 1 and res[False][4] == 3, (n, h, w, c, res[True][4], res[False][4])
+            tol = 4e-3 if bf16 else 2e-5
+            assert rel(res[True][0], res[False][0]) < tol, (n, h, w, c, rel(res[True][0], res[False][0]))
+            if with_mod:
+                assert rel(res[True][1], res[False][1]) < 1e-5
+            assert rel(res[True][2], res[False][2]) < 1e-5 and rel(res[True][3], res[False][3]) < 1e-5
+            if not bf16:       # autograd of the same function on the same inputs
+                yr = y.view(n, hw, c).permute(0, 2, 1).clone().requires_grad_(True)
+                gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+                gn = torch.nn.functional.group_norm(yr, 32, gr, br, 1e-5)
+                if with_mod:
+                    mr = mod.clone().requires_grad_(True)
+                    out = gn * mr[:, :, None] + mr[:, :, None]
+                else:
+                    out = gn
+                up = dout.view(n, hw, c).permute(0, 2, 1)
+                out.backward(up)
+                want = yr.grad.permute(0, 2, 1).reshape(rows, c)
+                if with_z:
+                    zz = z.float()
+                    sg = torch.sigmoid(zz)
+                    want = want * (sg * (1 + zz * (1 - sg)))
+                assert rel(res[True][0], want) < 2e-4, (n, h, w, c, rel(res[True][0], want))
+                assert rel(res[True][2], gr.grad) < 1e-4 and rel(res[True][3], br.grad) < 1e-4
+                if with_mod:
+                    assert rel(res[True][1], mr.grad) < 1e-4
+        first = None
+        dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+        was, ops.GN_COOP_BWD[0] = ops.GN_COOP_BWD[0], True
+        try:
+            for i in range(200):
+                dz, _ = ops.gn_adagn_bwd(dout, y, z, n, hw, gamma, beta, None, mean, rstd, dg, db)
+                if i == 0:
+                    first = dz.clone()
+        finally:
+            ops.GN_COOP_BWD[0] = was
+        assert rel(dz.float(), first.float()) < (4e-3 if bf16 else 1e-5)      # (the group pair's atomics arrive in any order)
+        torch.cuda.synchronize()
+        assert int(ops._gn_coop_state(dev).to(torch.int32).abs().sum()) == 0
+        assert float(ops.GNWS.get(n * c * 8, dev).abs().sum()) == 0.0
+
+
 def test_launch_plan_replays_the_sampling_step(dev, O):
     """sdm_plan_begin / _end / _run: the captured DDPM / DDIM step replayed from the C-side launch plan gives the samples of
     graph replay and of eager launching (same Philox key), a plan holds exactly the library launches of one step, and a
