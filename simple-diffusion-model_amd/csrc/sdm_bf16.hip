@@ -46,20 +46,37 @@ __device__ __forceinline__ void wait_vmcnt_bf() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Fragment reads the compiler does not see (ds_read_b128 in inline asm) with hand-counted waits.  Left to the compiler,
+// the wait in front of an MFMA group is s_waitcnt lgkmcnt(0) -- it also waits for the NEXT group's fragments, issued just
+// before (its scoreboard cannot count across the DMA-issuing branch of the loop) -- so every other group paid a full LDS
+// round trip.  LDS reads return in order: "at most N outstanding" with N = the reads issued after the set needed is exact.
+template <int OFF>
+__device__ __forceinline__ void ds_read128_bf(f32x4& v, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt_bf() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // out[m][n] = act(alpha * sum_tap sum_k A[row(m,tap)][k] * B[tap][n][k] + bias[n]) (+ res) ; see sdm_igemm_desc.
 // 256 threads = 2x2 waves, each wave owns (BM/2)x(BN/2).
 // FAST: K and the concat split are multiples of the 64-element K-step, so a K-step never straddles the reduction end or
 // the two concatenated sources; the DMA addresses are then per-lane pointers advanced by one add per K-step (rows outside
 // the image point at a zero chunk with step 0) and rebuilt only when the (tap, source) segment changes.
-template <int BM, int BN, int WM, int WN, int NBUF, bool FAST>
+template <int BM, int BN, int WM, int WN, int NBUF, bool FAST, bool XS, int KE = 64>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch L) {
   const sdm_igemm_desc& d = L.d;
   constexpr int NT = 64 * WM * WN;              // threads: WM x WN waves, each owning (BM/WM) x (BN/WN)
-  constexpr int RA = NT / 8;                    // tile rows covered by one pass of the NT threads (8 chunks per row)
+  constexpr int RF = KE / 2;                    // floats per LDS tile row (a K-step is KE bf16 = 128 or 64 bytes per row)
+  constexpr int CPR = KE / 8;                   // 16-byte chunks per row
+  constexpr int KG = KE / 16;                   // MFMA k-groups per K-step
+  static_assert(KE == 64 || KE == 32, "K-step");
+  constexpr int RA = NT / CPR;                  // tile rows covered by one pass of the NT threads
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr int AIT = BM / RA, BIT = BN / RA;
   static_assert(RA % 16 == 0 && BM % RA == 0 && BN % RA == 0, "pass geometry");
-  constexpr int A_TILE = BM * ROWF, B_TILE = BN * ROWF;
+  constexpr int A_TILE = BM * RF, B_TILE = BN * RF;
   constexpr int G = AIT + BIT;
   constexpr int PD = NBUF - 1;
   static_assert(PD >= 1 && PD <= 5, "ring depth");
@@ -81,9 +98,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
   const bf16_t* bw = (const bf16_t*)d.b + b0 * d.b_bs0 + b1 * d.b_bs1;
   const int HtWt = d.Ht * d.Wt;
   const int K = d.K, N = d.N, csplit = d.a.csplit;
-  const int arow = tid >> 3;
-  const int cc8 = 8 * ((tid & 7) ^ ((arow >> 1) & 7));   // logical chunk (in elements) behind this lane's physical slot
-  const int sw_l = (l31 >> 1) & 7;
+  // XOR swizzle of the 16-byte chunks inside a row, so that the 16 lanes of a ds_read_b128 group fall on 16 different
+  // slots of the 256-byte bank row: 128-byte rows (two per bank row): chunk ^ ((row >> 1) & 7); 64-byte rows (four per bank
+  // row): chunk ^ ((row >> 2) & 3)
+  const int arow = tid / CPR;
+  const int cc8 = KE == 64 ? 8 * ((tid & 7) ^ ((arow >> 1) & 7)) : 8 * ((tid & 3) ^ ((arow >> 2) & 3));   // logical chunk (in elements) behind this lane's physical slot
+  const int sw_l = KE == 64 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;
   const bf16_t* zero = (const bf16_t*)g_zero_chunk_bf;
 
   for (int r = tid; r < BM; r += NT) {
@@ -138,7 +158,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
   const bf16_t* pb[BIT];
   bool bok[BIT];
   int astep[AIT], bstep[BIT];          // FAST: elements to advance per K-step (64, or 0 for the zero chunk)
-  const int kch0 = (csplit < K ? csplit : K) / BKE;   // FAST: K-steps served by the first source
+  const int kch0 = (csplit < K ? csplit : K) / KE;   // FAST: K-steps served by the first source
   // general path: per-tap pointers, every K-step re-derives source / validity / tail
   auto setup_tap = [&](int tp) {
     const int dy = s_tap[tp], dx = s_tap[SDM_MAX_TAPS + tp];
@@ -161,23 +181,23 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
   // FAST path: pointers of segment (tap tp, starting at K-step kc of that tap)
   auto setup_seg = [&](int tp, int kc) {
     const int dy = s_tap[tp], dx = s_tap[SDM_MAX_TAPS + tp];
-    const bf16_t* bt = bw + (long long)s_tap[2 * SDM_MAX_TAPS + tp] * d.b_tap_stride + kc * BKE + cc8;
+    const bf16_t* bt = bw + (long long)s_tap[2 * SDM_MAX_TAPS + tp] * d.b_tap_stride + kc * KE + cc8;
     const bool second = kc >= kch0;
 #pragma unroll
     for (int i = 0; i < AIT; ++i) {
       const int sy = a_ys[i] + dy, sx = a_xs[i] + dx;
       const bool ok = (unsigned)sy < (unsigned)d.a.H && (unsigned)sx < (unsigned)d.a.W;
       const long long row = a_base[i] + dy * d.a.W + dx;
-      const bf16_t* p = second ? a1 + row * d.a.ld1 + ((kc - kch0) * BKE + cc8) : a0 + row * d.a.ld0 + (kc * BKE + cc8);
+      const bf16_t* p = second ? a1 + row * d.a.ld1 + ((kc - kch0) * KE + cc8) : a0 + row * d.a.ld0 + (kc * KE + cc8);
       pa0[i] = ok ? p : zero;
-      astep[i] = ok ? BKE : 0;
+      astep[i] = ok ? KE : 0;
     }
 #pragma unroll
     for (int i = 0; i < BIT; ++i) {
       const int n = n0 + arow + RA * i;
       const bool ok = n < N;
       pb[i] = ok ? bt + (long long)n * d.ldb : zero;
-      bstep[i] = ok ? BKE : 0;
+      bstep[i] = ok ? KE : 0;
     }
   };
 
@@ -187,12 +207,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
     if (FAST) {
 #pragma unroll
       for (int i = 0; i < AIT; ++i) {
-        __builtin_amdgcn_global_load_lds((glb_ptr)pa0[i], (lds_ptr)(Ad + i * RA * ROWF), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)pa0[i], (lds_ptr)(Ad + i * RA * RF), 16, 0, 0);
         pa0[i] += astep[i];
       }
 #pragma unroll
       for (int i = 0; i < BIT; ++i) {
-        __builtin_amdgcn_global_load_lds((glb_ptr)pb[i], (lds_ptr)(Bd + i * RA * ROWF), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)pb[i], (lds_ptr)(Bd + i * RA * RF), 16, 0, 0);
         pb[i] += bstep[i];
       }
       return;
@@ -203,13 +223,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
       const bool use = aok[i] && c < K;
       const bf16_t* p = (c < csplit ? pa0[i] : pa1[i]) + c0;
       p = use ? p : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Ad + i * RA * ROWF), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Ad + i * RA * RF), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BIT; ++i) {
       const bool use = bok[i] && c < K;
       const bf16_t* p = use ? pb[i] + c0 : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Bd + i * RA * ROWF), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(Bd + i * RA * RF), 16, 0, 0);
     }
   };
 
@@ -242,50 +262,125 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
           setup_tap(++tp);
         }
       }
-      issue(kc * BKE, (issued - it0) % NBUF);
+      issue(kc * KE, (issued - it0) % NBUF);
     }
     ++issued;
   };
+  auto wait_tile = [&](int younger) {      // wait until at most `younger` K-steps' DMA groups of this lane are still in flight
+    if (PD >= 5 && younger >= 5) wait_vmcnt_bf<(PD >= 5 ? 5 : 0) * G>();
+    else if (PD >= 4 && younger == 4) wait_vmcnt_bf<(PD >= 4 ? 4 : 0) * G>();
+    else if (PD >= 3 && younger == 3) wait_vmcnt_bf<(PD >= 3 ? 3 : 0) * G>();
+    else if (PD >= 2 && younger == 2) wait_vmcnt_bf<(PD >= 2 ? 2 : 0) * G>();
+    else if (younger == 1) wait_vmcnt_bf<G>();
+    else wait_vmcnt_bf<0>();
+  };
+  // fragment reads run one k-group ahead of the matrix instructions (two register sets, order pinned): left to itself
+  // the compiler reads a group, drains the LDS queue and only then issues its MFMAs
+  f32x4 af[2][TM], bf[2][TN];
+  auto ldfrag = [&](const float* Ab, const float* Bb, int kg, int st) {
+    const int ph = ((kg * 2 + h) ^ sw_l) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[st][i] = *(const f32x4*)(Ab + i * 32 * RF + ph);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[st][j] = *(const f32x4*)(Bb + j * 32 * RF + ph);
+  };
+  auto mfmas = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[st][i]),
+                                                            __builtin_bit_cast(bf16x8, bf[st][j]), acc[i][j], 0, 0, 0);
+  };
+  const int frag_off_a = (wm * TM * 32 + l31) * RF, frag_off_b = (wn * TN * 32 + l31) * RF;
+
+  if (XS) {
+    // Cross-step schedule.  The per-step barrier sits in the MIDDLE of a K-step, behind three issued MFMA groups (the
+    // matrix pipe works through its backlog while the waves meet), and covers two things at once: tile it+1 has landed
+    // for every wave, and every wave has finished reading tile it (its last fragment group is read one group ahead).
+    // So the first fragment group of tile it+1 is read under the last MFMA group of tile it -- no exposed LDS latency at
+    // the step boundary -- and the ring slot of tile it takes the next DMA half a step earlier: all NBUF slots are in
+    // flight instead of NBUF-1.
+#pragma unroll
+    for (int p = 0; p < NBUF; ++p) issue_next();
+    {
+      const int y0 = (it1 - 1 - it0) < PD ? (it1 - 1 - it0) : PD;
+      wait_tile(y0);
+      __builtin_amdgcn_s_barrier();
+    }
+    const unsigned lds_a = (unsigned)(uintptr_t)(lds_ptr)(As + frag_off_a), lds_b = (unsigned)(uintptr_t)(lds_ptr)(Bs + frag_off_b);
+    auto ldfrag_x = [&](unsigned a_addr, unsigned b_addr, int kg, int st) {
+      const unsigned ph = (unsigned)(((kg * 2 + h) ^ sw_l) << 4);
+      const unsigned pa = a_addr + ph, pb = b_addr + ph;
+      ds_read128_bf<0>(af[st][0], pa);
+      if constexpr (TM > 1) ds_read128_bf<32 * RF * 4>(af[st][1], pa);
+      if constexpr (TM > 2) ds_read128_bf<2 * 32 * RF * 4>(af[st][2], pa);
+      if constexpr (TM > 3) ds_read128_bf<3 * 32 * RF * 4>(af[st][3], pa);
+      ds_read128_bf<0>(bf[st][0], pb);
+      if constexpr (TN > 1) ds_read128_bf<32 * RF * 4>(bf[st][1], pb);
+      if constexpr (TN > 2) ds_read128_bf<2 * 32 * RF * 4>(bf[st][2], pb);
+      if constexpr (TN > 3) ds_read128_bf<3 * 32 * RF * 4>(bf[st][3], pb);
+    };
+    auto pin = [&](int st) {     // the set's registers are "rewritten" here: its MFMAs cannot move above the wait in front
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[st][i]));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bf[st][j]));
+    };
+    static_assert(TM <= 4 && TN <= 4, "fragment sets");
+    ldfrag_x(lds_a, lds_b, 0, 0);
+    for (int it = it0; it < it1; ++it) {
+      const int buf = (it - it0) % NBUF, nbuf = (it + 1 - it0) % NBUF;
+      const unsigned a_cur = lds_a + (unsigned)(buf * A_TILE * 4), b_cur = lds_b + (unsigned)(buf * B_TILE * 4);
+      const bool more = it + 1 < it1;
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) {
+        if (kg < KG - 1) {
+          ldfrag_x(a_cur, b_cur, kg + 1, (kg + 1) & 1);
+          wait_lgkmcnt_bf<TM + TN>();            // everything older than the reads just issued: set kg & 1 is complete
+        } else if (more) {
+          // (set kg & 1 was complete at the mid-step wait below)
+          ldfrag_x(lds_a + (unsigned)(nbuf * A_TILE * 4), lds_b + (unsigned)(nbuf * B_TILE * 4), 0, 0);
+        } else {
+          wait_lgkmcnt_bf<0>();
+        }
+        pin(kg & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(kg & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kg == KG - 2 && more) {
+          const int y = (it1 - 2 - it) < (PD - 1) ? (it1 - 2 - it) : (PD - 1);
+          wait_tile(y);
+          wait_lgkmcnt_bf<0>();                                  // this wave's reads of tile `it` are complete
+          __builtin_amdgcn_s_barrier();
+          issue_next();                                          // into the slot of tile `it`
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int p = 0; p < PD; ++p) issue_next();
 
   for (int it = it0; it < it1; ++it) {
     const int buf = (it - it0) % NBUF;
     const int younger = (it1 - 1 - it) < (PD - 1) ? (it1 - 1 - it) : (PD - 1);
-    if (PD >= 5 && younger >= 4) wait_vmcnt_bf<(PD >= 5 ? 4 : 0) * G>();
-    else if (PD >= 4 && younger == 3) wait_vmcnt_bf<(PD >= 4 ? 3 : 0) * G>();
-    else if (younger >= 2) wait_vmcnt_bf<2 * G>();
-    else if (younger == 1) wait_vmcnt_bf<G>();
-    else wait_vmcnt_bf<0>();
+    wait_tile(younger);
     __builtin_amdgcn_s_barrier();   // tile `it` visible to all waves; ring slot of tile it-1 is free again
-    const float* Ab = As + buf * A_TILE + (wm * TM * 32 + l31) * ROWF;
-    const float* Bb = Bs + buf * B_TILE + (wn * TN * 32 + l31) * ROWF;
-    // fragment reads run one k-group ahead of the matrix instructions (two register sets, order pinned): left to itself
-    // the compiler reads a group, drains the LDS queue and only then issues its MFMAs
-    f32x4 af[2][TM], bf[2][TN];
-    auto ldfrag = [&](int kg, int st) {
-      const int ph = ((kg * 2 + h) ^ sw_l) * 4;
+    const float* Ab = As + buf * A_TILE + frag_off_a;
+    const float* Bb = Bs + buf * B_TILE + frag_off_b;
+    ldfrag(Ab, Bb, 0, 0);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[st][i] = *(const f32x4*)(Ab + i * 32 * ROWF + ph);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[st][j] = *(const f32x4*)(Bb + j * 32 * ROWF + ph);
-    };
-    ldfrag(0, 0);
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      if (kg < 3) ldfrag(kg + 1, (kg + 1) & 1);
+    for (int kg = 0; kg < KG; ++kg) {
+      if (kg < KG - 1) ldfrag(Ab, Bb, kg + 1, (kg + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[kg & 1][i]),
-                                                              __builtin_bit_cast(bf16x8, bf[kg & 1][j]), acc[i][j], 0, 0, 0);
+      mfmas(kg & 1);
       __builtin_amdgcn_sched_barrier(0);
       // the DMA of K-step it+PD is issued in the shadow of the first MFMA group (the matrix pipe runs them
       // asynchronously), not between the barrier and the first fragment reads
       if (kg == 0) issue_next();
     }
+  }
   }
 
   // ---- epilogue
@@ -354,9 +449,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
     // 2-byte stores; the ring (no longer needed) is reused as an fp32 [BM][BN] tile so that every lane finishes 4
     // consecutive columns and stores 8 bytes (16 for fp32 scores), rows fully coalesced.
     // A tile larger than the ring (256x256) is staged in SL row slabs, each the i-th 32-row blocks of every wave row.
-    constexpr int SL = ((size_t)BM * BN <= (size_t)NBUF * (BM + BN) * ROWF) ? 1 : ((size_t)BM * BN / 2 <= (size_t)NBUF * (BM + BN) * ROWF ? 2 : TM);
+    constexpr int SL = ((size_t)BM * BN <= (size_t)NBUF * (BM + BN) * RF) ? 1 : ((size_t)BM * BN / 2 <= (size_t)NBUF * (BM + BN) * RF ? 2 : TM);
     constexpr int TMS = TM / SL;             // 32-row blocks per wave and slab
-    static_assert(TM % SL == 0 && (size_t)(BM / SL) * BN <= (size_t)NBUF * (BM + BN) * ROWF, "output slab must fit in the ring");
+    static_assert(TM % SL == 0 && (size_t)(BM / SL) * BN <= (size_t)NBUF * (BM + BN) * RF, "output slab must fit in the ring");
     float* Ct = smem;
     constexpr int C4 = BN / 4;
     static_assert(NT % C4 == 0, "a thread keeps one column quad across its rows");
@@ -905,11 +1000,13 @@ static void bf_plan(const sdm_igemm_desc* d, bool big_ok, int* cfg, int* splitk,
   *ws_need = sk > 1 ? (size_t)out_rows * d->batch * d->N * sizeof(float) : 0;
 }
 
-template <int BM, int BN, int WM, int WN, int NBUF, bool FAST>
-static int launch_bf(const BfLaunch& L, int ntm, hipStream_t st) {
-  constexpr size_t lds = (size_t)NBUF * (BM + BN) * ROWF * sizeof(float) + BM * sizeof(long long) + 3 * SDM_MAX_TAPS * sizeof(int);
+template <int BM, int BN, int WM, int WN, int NBUF, bool FAST, bool XS = false, int KE = 64>
+static int launch_bf(const BfLaunch& L0, int ntm, hipStream_t st) {
+  constexpr size_t lds = (size_t)NBUF * (BM + BN) * (KE / 2) * sizeof(float) + BM * sizeof(long long) + 3 * SDM_MAX_TAPS * sizeof(int);
+  BfLaunch L = L0;
+  L.kchunks = cdiv(L.d.K, KE);
   static bool attr_set = false;
-  auto kern = igemm_bf16_kernel<BM, BN, WM, WN, NBUF, FAST>;
+  auto kern = igemm_bf16_kernel<BM, BN, WM, WN, NBUF, FAST, XS, KE>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
@@ -1085,7 +1182,12 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
       return gs ? SDM_STATS_DONE : SDM_OK;
     }
   }
-  if (cfg == 0) rc = fast ? launch_bf<128, 128, 2, 2, 2, true>(L, ntm, st) : launch_bf<128, 128, 2, 2, 2, false>(L, ntm, st);
+  // cross-step schedule (barrier in the middle of a K-step, first fragments of the next tile read under the last MFMA
+  // group, all ring slots in flight): SDM_BF16_XS=0 selects the step-boundary barrier
+  static const char* xs_s = getenv("SDM_BF16_XS");
+  const bool xs = fast && !(xs_s && xs_s[0] == '0');
+  if (cfg == 0) rc = fast ? (xs ? launch_bf<128, 128, 2, 2, 2, true, true>(L, ntm, st) : launch_bf<128, 128, 2, 2, 2, true>(L, ntm, st))
+                          : launch_bf<128, 128, 2, 2, 2, false>(L, ntm, st);
   else if (cfg == 1) {
     // EXPERIMENT, opt-in (SDM_BF16_DEEP=1): at most one workgroup per CU in the grid (the N=1..4 sampling step) -> ring 6
     // (96 KB, five K-steps in flight instead of two).  Measured neutral on MI355X (N=1 bf16 step 0.727 -> 0.732 ms, N=4
@@ -1094,10 +1196,16 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
     static const char* deep = getenv("SDM_BF16_DEEP");
     const long nblocks = (long)ntm * L.ntn * d->nphase * L.splitk * d->batch;
     if (fast && nblocks <= 256 && deep && deep[0] == '1') rc = launch_bf<64, 64, 2, 2, 6, true>(L, ntm, st);
-    else rc = fast ? launch_bf<64, 64, 2, 2, 3, true>(L, ntm, st) : launch_bf<64, 64, 2, 2, 3, false>(L, ntm, st);
+    else rc = fast ? (xs ? launch_bf<64, 64, 2, 2, 3, true, true>(L, ntm, st) : launch_bf<64, 64, 2, 2, 3, true>(L, ntm, st))
+                   : launch_bf<64, 64, 2, 2, 3, false>(L, ntm, st);
   }
-  else if (cfg == 2 && fast && L.vec_epi && L.splitk == 1) rc = launch_bf<256, 256, 2, 4, 2, true>(L, ntm, st);
-  else if (cfg == 3 && fast && L.vec_epi && L.splitk == 1) rc = launch_bf<256, 256, 4, 2, 2, true>(L, ntm, st);
+  else if (cfg == 2 && fast && L.vec_epi && L.splitk == 1) {
+    // SDM_BF16_KE=32: 32-element K-steps on a four-slot ring (three 32 KB tiles in flight instead of one 64 KB tile)
+    static const char* ke_s = getenv("SDM_BF16_KE");
+    if (xs && ke_s && atoi(ke_s) == 32) rc = launch_bf<256, 256, 2, 4, 4, true, true, 32>(L, ntm, st);
+    else rc = xs ? launch_bf<256, 256, 2, 4, 2, true, true>(L, ntm, st) : launch_bf<256, 256, 2, 4, 2, true>(L, ntm, st);
+  }
+  else if (cfg == 3 && fast && L.vec_epi && L.splitk == 1) rc = xs ? launch_bf<256, 256, 4, 2, 2, true, true>(L, ntm, st) : launch_bf<256, 256, 4, 2, 2, true>(L, ntm, st);
   else rc = sdm_set_error(SDM_ERR_ARG, "igemm_bf16: tile configuration %d needs the FAST path, the vector epilogue and no split-K", cfg);
   if (rc != SDM_OK) return rc;
   if (L.splitk > 1 && d->defer_epilogue) return SDM_DEFERRED;   // raw fp32 sums stay in ws for sdm_gn_apply_fused_bf16
