@@ -1672,7 +1672,7 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_bf16_kernel(void* __restr
                                                                    const float* __restrict__ mod, int mod_ns,
                                                                    const bf16_t* __restrict__ x0, long long ldx0,
                                                                    const bf16_t* __restrict__ x1, long long ldx1, int csplit,
-                                                                   bf16_t* __restrict__ out, long long ldo) {
+                                                                   bf16_t* __restrict__ out, long long ldo, int hold) {
   __shared__ double red[2][16];
   __shared__ float s_stat[2];
   const int n = blockIdx.x / groups, g = blockIdx.x % groups;
@@ -1681,6 +1681,26 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_bf16_kernel(void* __restr
   const long long tot4 = (long long)HW * q4;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   double s1 = 0.0, s2 = 0.0;
+  const bool held = hold && tot4 <= 1024 * 8;      // small maps: the values stay in registers between the two sweeps (see gn_apply_fused_kernel)
+  f32x4 hv[8];
+  if (held) {
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long e = threadIdx.x + (long long)u * 1024;
+      hv[u] = zero4;
+      if (e < tot4) {
+        const long long pix = sdm_idiv(e, q4);
+        const int c = (int)(e - pix * q4) * 4;
+        const f32x4 b = (raw && bias) ? *(const f32x4*)(bias + g * cpg + c) : zero4;
+        hv[u] = gnf16_value(src, base + pix * lds_ + c, raw, alpha, b, act);
+        p1 += (hv[u].x + hv[u].y) + (hv[u].z + hv[u].w);
+        p2 += (hv[u].x * hv[u].x + hv[u].y * hv[u].y) + (hv[u].z * hv[u].z + hv[u].w * hv[u].w);
+      }
+    }
+    s1 = p1;
+    s2 = p2;
+  } else {
   for (long long e0 = threadIdx.x; e0 < tot4; e0 += 1024 * 8) {
     float p1 = 0.f, p2 = 0.f;
 #pragma unroll
@@ -1697,6 +1717,7 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_bf16_kernel(void* __restr
     }
     s1 += p1;
     s2 += p2;
+  }
   }
   s1 = wave_sum_d(s1);
   s2 = wave_sum_d(s2);
@@ -1716,13 +1737,11 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_bf16_kernel(void* __restr
   }
   __syncthreads();
   const float mu = s_stat[0], rstd = s_stat[1];
-  for (long long e = threadIdx.x; e < tot4; e += 1024) {
+  auto emit = [&](long long e, const f32x4 v) {
     const long long pix = sdm_idiv(e, q4);
     const int c = (int)(e - pix * q4) * 4;
     const int ch = g * cpg + c;
     const long long si = base + pix * lds_ + c;
-    const f32x4 b = (raw && bias) ? *(const f32x4*)(bias + ch) : zero4;
-    const f32x4 v = gnf16_value(src, si, raw, alpha, b, act);
     if (raw) *(f32x4*)((float*)src + si) = zero4;        // the split-K scratch goes back zero-filled
     const f32x4 ga = *(const f32x4*)(gamma + ch), be = *(const f32x4*)(beta + ch);
     f32x4 o;
@@ -1744,6 +1763,20 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_bf16_kernel(void* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) ov[i] = f2bf(o[i]);
     *(u16x4*)(out + row * ldo + ch) = ov;
+  };
+  if (held) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long e = threadIdx.x + (long long)u * 1024;
+      if (e < tot4) emit(e, hv[u]);
+    }
+  } else {
+    for (long long e = threadIdx.x; e < tot4; e += 1024) {
+      const long long pix = sdm_idiv(e, q4);
+      const int c = (int)(e - pix * q4) * 4;
+      const f32x4 b = (raw && bias) ? *(const f32x4*)(bias + g * cpg + c) : zero4;
+      emit(e, gnf16_value(src, base + pix * lds_ + c, raw, alpha, b, act));
+    }
   }
 }
 
@@ -1764,7 +1797,8 @@ extern "C" int sdm_gn_apply_fused_bf16(const void* src, int64_t ld_src, int src_
   SDM_CHECK_ARG(act >= 0 && act <= 2, "gn_apply_fused_bf16: bad act");
   SDM_LAUNCH(gn_apply_fused_bf16_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, (void*)src,
                      (long long)ld_src, src_raw, alpha, bias, act, HW, C, groups, eps, gamma, beta, mod, mod_nstride,
-                     (const bf16_t*)x0, (long long)ldx0, (const bf16_t*)x1, (long long)ldx1, csplit, (bf16_t*)out, (long long)ldo);
+                     (const bf16_t*)x0, (long long)ldx0, (const bf16_t*)x1, (long long)ldx1, csplit, (bf16_t*)out, (long long)ldo,
+                     sdm_gn_hold());
   SDM_CHECK_LAUNCH("gn_apply_fused_bf16");
   return SDM_OK;
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "sdm_hip.h"
@@ -113,6 +114,12 @@ static inline void sdm_launch(void (*kern)(P...), dim3 grid, dim3 block, size_t 
   (void)hipLaunchKernel((const void*)kern, grid, block, ptrs, lds, st);
 }
 #define SDM_LAUNCH(kern, grid, block, lds, st, ...) sdm_launch(kern, grid, block, lds, st, __VA_ARGS__)
+
+// fused GroupNorm tails keep a small map's values in registers between their two sweeps (SDM_GN_HOLD=0: re-read, A/B)
+inline int sdm_gn_hold() {
+  static const char* e = getenv("SDM_GN_HOLD");
+  return !(e && e[0] == '0');
+}
 
 // ---- optional per-launch event timing (sdm_prof_begin / sdm_prof_end) ----
 bool sdm_prof_on();

@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_kernel(float* __restrict_
                                                               const float* __restrict__ x1, long long ldx1, int csplit,
                                                               float* __restrict__ out, long long ldo,
                                                               float* __restrict__ z_out, float* __restrict__ y_out, long long ldy,
-                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out, int hold) {
   __shared__ double red[2][16];
   __shared__ float s_stat[2];
   const int n = blockIdx.x / groups, g = blockIdx.x % groups;
@@ -1365,6 +1365,34 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_kernel(float* __restrict_
   const long long tot4 = (long long)HW * q4;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   double s1 = 0.0, s2 = 0.0;
+  // Small maps (<= 8 channel quads per thread: everything below 64x64 at the U-Net's widths): the source values stay in
+  // registers between the statistics sweep and the apply sweep -- one dependent trip to memory less in a launch that is
+  // nothing but such trips (the N=1 sampling step runs twelve of these per denoise step)
+  const bool held = hold && tot4 <= 1024 * 8;
+  f32x4 sv[8];
+  if (held) {
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long e = threadIdx.x + (long long)u * 1024;
+      sv[u] = zero4;
+      if (e < tot4) {
+        const long long pix = sdm_idiv(e, q4);
+        const int c = (int)(e - pix * q4) * 4;
+        const f32x4 b = (raw && bias) ? *(const f32x4*)(bias + g * cpg + c) : zero4;
+        sv[u] = *(const f32x4*)(base + pix * lds_ + c);
+        f32x4 v = sv[u];
+        if (raw) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = sdm_act(v[i] * alpha + b[i], act);
+        }
+        p1 += (v.x + v.y) + (v.z + v.w);
+        p2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    }
+    s1 = p1;
+    s2 = p2;
+  } else {
   for (long long e0 = threadIdx.x; e0 < tot4; e0 += 1024 * 8) {
     float p1 = 0.f, p2 = 0.f;
 #pragma unroll
@@ -1381,6 +1409,7 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_kernel(float* __restrict_
     }
     s1 += p1;
     s2 += p2;
+  }
   }
   s1 = wave_sum_d(s1);
   s2 = wave_sum_d(s2);
@@ -1404,17 +1433,21 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_kernel(float* __restrict_
   }
   __syncthreads();
   const float mu = s_stat[0], rstd = s_stat[1];
-  for (long long e = threadIdx.x; e < tot4; e += 1024) {
+  auto emit = [&](long long e, const f32x4 srcv) {
     const long long pix = sdm_idiv(e, q4);
     const int c = (int)(e - pix * q4) * 4;
     const int ch = g * cpg + c;
     float* sp = base + pix * lds_ + c;
     const f32x4 b = (raw && bias) ? *(const f32x4*)(bias + ch) : zero4;
-    f32x4 v = gnf_value(sp, raw, alpha, b, act);
+    f32x4 v = srcv;
+    if (raw) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = sdm_act(v[i] * alpha + b[i], act);
+    }
     if (raw && y_out) {      // training: the conv's own outputs (pre-activation and activated rows) for its backward
       const long long yo = ((long long)n * HW + pix) * ldy + ch;
       if (z_out) {
-        f32x4 zv = *(const f32x4*)sp;
+        f32x4 zv = srcv;
 #pragma unroll
         for (int i = 0; i < 4; ++i) zv[i] = zv[i] * alpha + b[i];
         *(f32x4*)(z_out + yo) = zv;
@@ -1439,6 +1472,18 @@ __global__ __launch_bounds__(1024) void gn_apply_fused_kernel(float* __restrict_
     const long long row = (long long)n * HW + pix;
     if (x0) o += (ch < csplit) ? *(const f32x4*)(x0 + row * ldx0 + ch) : *(const f32x4*)(x1 + row * ldx1 + (ch - csplit));
     *(f32x4*)(out + row * ldo + ch) = o;
+  };
+  if (held) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long e = threadIdx.x + (long long)u * 1024;
+      if (e < tot4) emit(e, sv[u]);
+    }
+  } else {
+    for (long long e = threadIdx.x; e < tot4; e += 1024) {
+      const long long pix = sdm_idiv(e, q4);
+      emit(e, *(const f32x4*)(base + pix * lds_ + (int)(e - pix * q4) * 4));
+    }
   }
 }
 
@@ -1477,7 +1522,7 @@ extern "C" int sdm_gn_apply_fused_train(const float* src, int64_t ld_src, int sr
   SDM_CHECK_ARG(act >= 0 && act <= 2, "gn_apply_fused: bad act");
   SDM_LAUNCH(gn_apply_fused_kernel, dim3(images * groups), dim3(1024), 0, (hipStream_t)s, (float*)src, (long long)ld_src,
                      src_raw, alpha, bias, act, HW, C, groups, eps, gamma, beta, mod, mod_nstride, x0, (long long)ldx0, x1,
-                     (long long)ldx1, csplit, out, (long long)ldo, z_out, y_out, (long long)ldy, mean, rstd);
+                     (long long)ldx1, csplit, out, (long long)ldo, z_out, y_out, (long long)ldy, mean, rstd, sdm_gn_hold());
   SDM_CHECK_LAUNCH("gn_apply_fused");
   return SDM_OK;
 }
