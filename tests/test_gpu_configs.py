@@ -304,3 +304,58 @@ def test_c5_sr_training_step_256_bf16(dev, O):
     # ONE image: a weight gradient averages over a single sample, and the tensors furthest from the loss (down path, ~40
     # bf16 roundings of the activation gradient behind them) reach 2.7e-2 (median 6e-3); C4 at N=2 holds 2e-2
     assert _check_grads_bf16(O, cfg, net, grads, ref_g, lim=3e-2) == 148 - 16
+
+
+# ------------------------------------------------------------------------------------------------ full batch sizes: properties
+@pytest.mark.parametrize("which,dtype", [("c4", "f32"), ("c4", "bf16"), ("c5", "f32"), ("c5", "bf16")])
+def test_full_batch_sizes_through_size_independent_properties(dev, O, which, dtype):
+    """BASELINE's per-GPU batch sizes (C4: 32 images of 128x128; C5: 8 images of 256x256, 6-channel SR net) are out of the CPU
+    oracle's reach, and the kernels plan differently there (tile sizes, split-K, 256x256 bf16 tiles, cooperative GroupNorm
+    tail).  Two properties tie the full-size launches to the small-batch ones the oracle pins above:
+      batch invariance -- image i's output does not depend on its batch mates: the batch-N forward equals the forwards of its
+        pairs (C4) / single images (C5), row for row;
+      gradient linearity -- the mean-loss gradient of the full batch equals the mean of the gradients of its quarters.
+    fp32 within summation order (observed 3e-7 / 5e-6; gates 5e-6 / 1e-4); bf16 within bf16 rounding of differently tiled
+    sums (observed 9e-4 / 1.2e-2; gates 5e-3 / 3e-2)."""
+    n, res, over, sub = (32, 128, {}, 2) if which == "c4" else (8, 256, dict(in_channel=6, image_recon=True), 1)
+    cfg, net, _ = standard(O, **over)
+    bf = dtype == "bf16"
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, cfg["in_channel"], res, res, generator=g).cuda()
+    t = torch.randint(1, 1000, (n,), generator=g).cuda()
+    target = torch.randn(n, 3, res, res, generator=g).cuda()
+    net.eval()
+    if bf:
+        net.set_inference_dtype(torch.bfloat16)
+    with torch.no_grad():
+        full = net(x, t, None).float()
+        parts = torch.cat([net(x[i:i + sub], t[i:i + sub], None).float() for i in range(0, n, sub)], dim=0)
+    assert bool(torch.isfinite(full).all())
+    worst = max(rel(full[i], parts[i]) for i in range(n))
+    assert worst < (5e-3 if bf else 5e-6), worst
+    print(f"{which} {dtype}: batch invariance worst rel-L2 {worst:.2e}")
+    # gradient linearity over quarters of the batch (mean-reduced MSE: the full gradient is the mean of the four)
+    net.train()
+    if bf:
+        net.set_training_dtype(torch.bfloat16)
+    _, grads = net.loss_and_grads(x, t, None, target)
+    full_g = {p: v.clone() for p, v in grads.items() if v is not None}
+    q = n // 4
+    acc = {p: torch.zeros_like(v) for p, v in full_g.items()}
+    for i in range(0, n, q):
+        _, gq = net.loss_and_grads(x[i:i + q], t[i:i + q], None, target[i:i + q])
+        for p in acc:
+            acc[p] += gq[p] / 4
+    dead = set(O.dead_param_names(cfg))
+    names = {p: k for k, p in net.named_parameters()}
+    bad, worst_g = [], 0.0
+    for p, v in full_g.items():
+        k = names[p]
+        if k in dead or (".conv_block_" in k and k.endswith("conv_layer.0.bias")):      # cancelling sums (see check_grads)
+            continue
+        r = rel(v, acc[p])
+        worst_g = max(worst_g, r)
+        if r > (3e-2 if bf else 1e-4):
+            bad.append((k, r))
+    print(f"{which} {dtype}: gradient linearity worst rel-L2 {worst_g:.2e}")
+    assert not bad, bad[:8]
