@@ -307,9 +307,10 @@ def test_c5_sr_training_step_256_bf16(dev, O):
 
 
 # ------------------------------------------------------------------------------------------------ full batch sizes: properties
-@pytest.mark.parametrize("which,dtype", [("c4", "f32"), ("c4", "bf16"), ("c5", "f32"), ("c5", "bf16")])
+@pytest.mark.parametrize("which,dtype", [("c4", "f32"), ("c4", "bf16"), ("c5", "f32"), ("c5", "bf16"), ("c3", "bf16")])
 def test_full_batch_sizes_through_size_independent_properties(dev, O, which, dtype):
-    """BASELINE's per-GPU batch sizes (C4: 32 images of 128x128; C5: 8 images of 256x256, 6-channel SR net) are out of the CPU
+    """BASELINE's per-GPU batch sizes (C3: 64 + 64 guidance images of 128x128; C4: 32 images of 128x128; C5: 8 images of
+    256x256, 6-channel SR net) are out of the CPU
     oracle's reach, and the kernels plan differently there (tile sizes, split-K, 256x256 bf16 tiles, cooperative GroupNorm
     tail).  Two properties tie the full-size launches to the small-batch ones the oracle pins above:
       batch invariance -- image i's output does not depend on its batch mates: the batch-N forward equals the forwards of its
@@ -317,23 +318,31 @@ def test_full_batch_sizes_through_size_independent_properties(dev, O, which, dty
       gradient linearity -- the mean-loss gradient of the full batch equals the mean of the gradients of its quarters.
     fp32 within summation order (observed 3e-7 / 5e-6; gates 5e-6 / 1e-4); bf16 within bf16 rounding of differently tiled
     sums (observed 9e-4 / 1.2e-2; gates 5e-3 / 3e-2)."""
-    n, res, over, sub = (32, 128, {}, 2) if which == "c4" else (8, 256, dict(in_channel=6, image_recon=True), 1)
+    n, res, over, sub = {"c4": (32, 128, {}, 2), "c5": (8, 256, dict(in_channel=6, image_recon=True), 1),
+                         "c3": (128, 128, dict(cond_dim=10), 2)}[which]     # C3: 64 images + their unconditional twins (CFG)
     cfg, net, _ = standard(O, **over)
     bf = dtype == "bf16"
     g = torch.Generator().manual_seed(77)
     x = torch.randn(n, cfg["in_channel"], res, res, generator=g).cuda()
     t = torch.randint(1, 1000, (n,), generator=g).cuda()
     target = torch.randn(n, 3, res, res, generator=g).cuda()
+    lab = None
+    if which == "c3":
+        lab = torch.nn.functional.one_hot(torch.randint(0, 10, (n,), generator=g), 10).float().cuda()
+        lab[n // 2:] = 0.0                                     # the unconditional half of a guidance batch
     net.eval()
     if bf:
         net.set_inference_dtype(torch.bfloat16)
     with torch.no_grad():
-        full = net(x, t, None).float()
-        parts = torch.cat([net(x[i:i + sub], t[i:i + sub], None).float() for i in range(0, n, sub)], dim=0)
+        full = net(x, t, lab).float()
+        parts = torch.cat([net(x[i:i + sub], t[i:i + sub], None if lab is None else lab[i:i + sub]).float()
+                           for i in range(0, n, sub)], dim=0)
     assert bool(torch.isfinite(full).all())
     worst = max(rel(full[i], parts[i]) for i in range(n))
     assert worst < (5e-3 if bf else 5e-6), worst
     print(f"{which} {dtype}: batch invariance worst rel-L2 {worst:.2e}")
+    if which == "c3":          # a sampling configuration: no training step to check
+        return
     # gradient linearity over quarters of the batch (mean-reduced MSE: the full gradient is the mean of the four)
     net.train()
     if bf:
