@@ -25,6 +25,7 @@ struct BfLaunch {
   long long out_rows;   // output rows of ONE batch entry (split-K scratch is [batch][out_rows][N])
   int pow2, lw, lhw;    // prologue shortcuts, as in sdm_igemm.hip: Wt == 1 << lw, Ht * Wt == 1 << lhw
   int plain_out;        // output row == tile-grid row
+  int pp;               // 8-wave tiles: ping-pong schedule of the two 4-wave halves (see the kernel)
 };
 
 static inline int ilog2_exact_bf(long v) {
@@ -64,7 +65,7 @@ __device__ __forceinline__ void wait_lgkmcnt_bf() {
 // FAST: K and the concat split are multiples of the 64-element K-step, so a K-step never straddles the reduction end or
 // the two concatenated sources; the DMA addresses are then per-lane pointers advanced by one add per K-step (rows outside
 // the image point at a zero chunk with step 0) and rebuilt only when the (tap, source) segment changes.
-template <int BM, int BN, int WM, int WN, int NBUF, bool FAST, bool XS, int KE = 64>
+template <int BM, int BN, int WM, int WN, int NBUF, bool FAST, bool XS, int KE = 64, bool PP = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch L) {
   const sdm_igemm_desc& d = L.d;
   constexpr int NT = 64 * WM * WN;              // threads: WM x WN waves, each owning (BM/WM) x (BN/WN)
@@ -295,19 +296,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
   const int frag_off_a = (wm * TM * 32 + l31) * RF, frag_off_b = (wn * TN * 32 + l31) * RF;
 
   if (XS) {
-    // Cross-step schedule.  The per-step barrier sits in the MIDDLE of a K-step, behind three issued MFMA groups (the
-    // matrix pipe works through its backlog while the waves meet), and covers two things at once: tile it+1 has landed
-    // for every wave, and every wave has finished reading tile it (its last fragment group is read one group ahead).
-    // So the first fragment group of tile it+1 is read under the last MFMA group of tile it -- no exposed LDS latency at
-    // the step boundary -- and the ring slot of tile it takes the next DMA half a step earlier: all NBUF slots are in
-    // flight instead of NBUF-1.
-#pragma unroll
-    for (int p = 0; p < NBUF; ++p) issue_next();
-    {
-      const int y0 = (it1 - 1 - it0) < PD ? (it1 - 1 - it0) : PD;
-      wait_tile(y0);
-      __builtin_amdgcn_s_barrier();
-    }
     const unsigned lds_a = (unsigned)(uintptr_t)(lds_ptr)(As + frag_off_a), lds_b = (unsigned)(uintptr_t)(lds_ptr)(Bs + frag_off_b);
     auto ldfrag_x = [&](unsigned a_addr, unsigned b_addr, int kg, int st) {
       const unsigned ph = (unsigned)(((kg * 2 + h) ^ sw_l) << 4);
@@ -328,33 +316,90 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
       for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bf[st][j]));
     };
     static_assert(TM <= 4 && TN <= 4, "fragment sets");
-    ldfrag_x(lds_a, lds_b, 0, 0);
-    for (int it = it0; it < it1; ++it) {
-      const int buf = (it - it0) % NBUF, nbuf = (it + 1 - it0) % NBUF;
-      const unsigned a_cur = lds_a + (unsigned)(buf * A_TILE * 4), b_cur = lds_b + (unsigned)(buf * B_TILE * 4);
-      const bool more = it + 1 < it1;
+    static_assert(!PP || (NT == 512 && KG == 4), "ping-pong: 8 waves, four k-groups per K-step");
+    if constexpr (PP) {
+      // Ping-pong of the two 4-wave halves of an 8-wave tile (waves w and w + 4 share a SIMD).  A K-step is two half-steps of
+      // two k-groups: LOAD = read the half-step's 12 fragments into the two register sets, MFMA = its 16 matrix instructions.
+      // Both halves meet at ONE barrier per K-step, but at different points of their programs:
+      //   half 0:  B | DMA  L0 M0 L1 M1 | B ...
+      //   half 1:  B | M1'  DMA L0 M0 L1 | B ...      (M1' = the last half-step of the PREVIOUS tile, read before the barrier)
+      // so after the barrier one wave of every SIMD has 16 MFMAs to issue while its partner issues the DMA and reads
+      // fragments, and they keep alternating until the next barrier: the matrix pipe is fed across the hand-off.  The barrier
+      // still means what it meant: tile `it` has landed for everybody, nobody reads tile it-1 any more (half 1 read its
+      // last fragments of it before arriving), so the DMA of tile it+PD may overwrite that slot.
 #pragma unroll
-      for (int kg = 0; kg < KG; ++kg) {
-        if (kg < KG - 1) {
-          ldfrag_x(a_cur, b_cur, kg + 1, (kg + 1) & 1);
-          wait_lgkmcnt_bf<TM + TN>();            // everything older than the reads just issued: set kg & 1 is complete
-        } else if (more) {
-          // (set kg & 1 was complete at the mid-step wait below)
-          ldfrag_x(lds_a + (unsigned)(nbuf * A_TILE * 4), lds_b + (unsigned)(nbuf * B_TILE * 4), 0, 0);
-        } else {
-          wait_lgkmcnt_bf<0>();
-        }
-        pin(kg & 1);
+      for (int p = 0; p < PD; ++p) issue_next();
+      const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+      auto loadh = [&](unsigned a_cur, unsigned b_cur, int half) {
+        ldfrag_x(a_cur, b_cur, 2 * half, 0);
+        ldfrag_x(a_cur, b_cur, 2 * half + 1, 1);
+      };
+      auto mfmah = [&]() {
+        wait_lgkmcnt_bf<0>();
+        pin(0);
+        pin(1);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(kg & 1);
+        mfmas(0);
+        mfmas(1);
         __builtin_amdgcn_sched_barrier(0);
-        if (kg == KG - 2 && more) {
-          const int y = (it1 - 2 - it) < (PD - 1) ? (it1 - 2 - it) : (PD - 1);
-          wait_tile(y);
-          wait_lgkmcnt_bf<0>();                                  // this wave's reads of tile `it` are complete
-          __builtin_amdgcn_s_barrier();
-          issue_next();                                          // into the slot of tile `it`
+      };
+      for (int it = it0; it < it1; ++it) {
+        const int buf = (it - it0) % NBUF;
+        const unsigned a_cur = lds_a + (unsigned)(buf * A_TILE * 4), b_cur = lds_b + (unsigned)(buf * B_TILE * 4);
+        const int younger = (it1 - 1 - it) < (PD - 1) ? (it1 - 1 - it) : (PD - 1);
+        wait_tile(younger);
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1 && it > it0) mfmah();       // M1' of the previous tile
+        issue_next();
+        loadh(a_cur, b_cur, 0);
+        mfmah();
+        loadh(a_cur, b_cur, 1);
+        if (grp == 0) mfmah();
+        else wait_lgkmcnt_bf<0>();               // this wave's reads of tile `it` are complete before it meets the others
+      }
+      if (grp == 1) mfmah();
+    } else {
+    // Cross-step schedule.  The per-step barrier sits in the MIDDLE of a K-step, behind three issued MFMA groups (the
+      // matrix pipe works through its backlog while the waves meet), and covers two things at once: tile it+1 has landed
+      // for every wave, and every wave has finished reading tile it (its last fragment group is read one group ahead).
+      // So the first fragment group of tile it+1 is read under the last MFMA group of tile it -- no exposed LDS latency at
+      // the step boundary -- and the ring slot of tile it takes the next DMA half a step earlier: all NBUF slots are in
+      // flight instead of NBUF-1.
+#pragma unroll
+      for (int p = 0; p < NBUF; ++p) issue_next();
+      {
+        const int y0 = (it1 - 1 - it0) < PD ? (it1 - 1 - it0) : PD;
+        wait_tile(y0);
+        __builtin_amdgcn_s_barrier();
+      }
+        ldfrag_x(lds_a, lds_b, 0, 0);
+      for (int it = it0; it < it1; ++it) {
+        const int buf = (it - it0) % NBUF, nbuf = (it + 1 - it0) % NBUF;
+        const unsigned a_cur = lds_a + (unsigned)(buf * A_TILE * 4), b_cur = lds_b + (unsigned)(buf * B_TILE * 4);
+        const bool more = it + 1 < it1;
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+          if (kg < KG - 1) {
+            ldfrag_x(a_cur, b_cur, kg + 1, (kg + 1) & 1);
+            wait_lgkmcnt_bf<TM + TN>();            // everything older than the reads just issued: set kg & 1 is complete
+          } else if (more) {
+            // (set kg & 1 was complete at the mid-step wait below)
+            ldfrag_x(lds_a + (unsigned)(nbuf * A_TILE * 4), lds_b + (unsigned)(nbuf * B_TILE * 4), 0, 0);
+          } else {
+            wait_lgkmcnt_bf<0>();
+          }
+          pin(kg & 1);
           __builtin_amdgcn_sched_barrier(0);
+          mfmas(kg & 1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kg == KG - 2 && more) {
+            const int y = (it1 - 2 - it) < (PD - 1) ? (it1 - 2 - it) : (PD - 1);
+            wait_tile(y);
+            wait_lgkmcnt_bf<0>();                                  // this wave's reads of tile `it` are complete
+            __builtin_amdgcn_s_barrier();
+            issue_next();                                          // into the slot of tile `it`
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
     }
@@ -1000,13 +1045,13 @@ static void bf_plan(const sdm_igemm_desc* d, bool big_ok, int* cfg, int* splitk,
   *ws_need = sk > 1 ? (size_t)out_rows * d->batch * d->N * sizeof(float) : 0;
 }
 
-template <int BM, int BN, int WM, int WN, int NBUF, bool FAST, bool XS = false, int KE = 64>
+template <int BM, int BN, int WM, int WN, int NBUF, bool FAST, bool XS = false, int KE = 64, bool PP = false>
 static int launch_bf(const BfLaunch& L0, int ntm, hipStream_t st) {
   constexpr size_t lds = (size_t)NBUF * (BM + BN) * (KE / 2) * sizeof(float) + BM * sizeof(long long) + 3 * SDM_MAX_TAPS * sizeof(int);
   BfLaunch L = L0;
   L.kchunks = cdiv(L.d.K, KE);
   static bool attr_set = false;
-  auto kern = igemm_bf16_kernel<BM, BN, WM, WN, NBUF, FAST, XS, KE>;
+  auto kern = igemm_bf16_kernel<BM, BN, WM, WN, NBUF, FAST, XS, KE, PP>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
@@ -1186,6 +1231,8 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
   // group, all ring slots in flight): SDM_BF16_XS=0 selects the step-boundary barrier
   static const char* xs_s = getenv("SDM_BF16_XS");
   const bool xs = fast && !(xs_s && xs_s[0] == '0');
+  static const char* pp_s = getenv("SDM_BF16_PP");         // 8-wave tiles: ping-pong of the two 4-wave halves ("0": off)
+  L.pp = (pp_s && pp_s[0] == '1') ? 1 : 0;
   if (cfg == 0) rc = fast ? (xs ? launch_bf<128, 128, 2, 2, 2, true, true>(L, ntm, st) : launch_bf<128, 128, 2, 2, 2, true>(L, ntm, st))
                           : launch_bf<128, 128, 2, 2, 2, false>(L, ntm, st);
   else if (cfg == 1) {
@@ -1202,7 +1249,8 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
   else if (cfg == 2 && fast && L.vec_epi && L.splitk == 1) {
     // SDM_BF16_KE=32: 32-element K-steps on a four-slot ring (three 32 KB tiles in flight instead of one 64 KB tile)
     static const char* ke_s = getenv("SDM_BF16_KE");
-    if (xs && ke_s && atoi(ke_s) == 32) rc = launch_bf<256, 256, 2, 4, 4, true, true, 32>(L, ntm, st);
+    if (xs && L.pp) rc = launch_bf<256, 256, 2, 4, 2, true, true, 64, true>(L, ntm, st);
+    else if (xs && ke_s && atoi(ke_s) == 32) rc = launch_bf<256, 256, 2, 4, 4, true, true, 32>(L, ntm, st);
     else rc = xs ? launch_bf<256, 256, 2, 4, 2, true, true>(L, ntm, st) : launch_bf<256, 256, 2, 4, 2, true>(L, ntm, st);
   }
   else if (cfg == 3 && fast && L.vec_epi && L.splitk == 1) rc = xs ? launch_bf<256, 256, 4, 2, 2, true, true>(L, ntm, st) : launch_bf<256, 256, 4, 2, 2, true>(L, ntm, st);
