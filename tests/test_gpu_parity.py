@@ -609,6 +609,25 @@ def test_training_step_hipgraph_replay_matches_eager(dev, O):
         if not torch.allclose(got, ref, rtol=1e-3, atol=5e-5):
             bad.append((k, float((got - ref).abs().max())))
     assert not bad, bad[:8]
+    # a bf16 no-grad forward in the same process must see the weights the replayed Adam wrote (the bf16 weight
+    # copies are tagged by ops.WEIGHT_EPOCH, which graph replay has to bump like the eager optimizer does)
+    net.eval()
+    net.set_inference_dtype(torch.bfloat16)
+    x = T(g["x0_0"]).cuda()
+    t = T(g["t_0"]).cuda()
+    lab = T(g["lab_0"]).cuda()
+    with torch.no_grad():
+        before = net(x, t, lab).float().clone()
+    net.train()
+    for i in range(3):
+        tr.step(T(g[f"x0_{i}"]).cuda(), T(g[f"lab_{i}"]).cuda(), eps=T(g[f"eps_{i}"]).cuda(), t=T(g[f"t_{i}"]).cuda())
+    net.eval()
+    with torch.no_grad():
+        after = net(x, t, lab).float()
+        net.set_inference_dtype(torch.float32)
+        after32 = net(x, t, lab).float()
+    assert rel(after, before) > 1e-3                      # three more lr=2e-3 steps moved the output ...
+    assert rel(after, after32) < 2e-2, rel(after, after32)  # ... and the bf16 forward follows the NEW weights
 
 
 # ------------------------------------------------------------------------------------------------
