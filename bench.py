@@ -447,6 +447,8 @@ def main():
     prof_steps = max(1, min(args.steps, 10))
     tr.step(x0)
     barrier()
+    # what an event pair adds to the launch it brackets (median over an empty kernel; still contains that kernel's own ~1-2 us)
+    bracket_ms = lib.prof_bracket_ms(_ops._stream(), 64)
     lib.prof_begin(200000)
     tp0 = time.perf_counter()
     for _ in range(prof_steps):
@@ -490,9 +492,19 @@ def main():
             break
         except Exception:
             pass
+    # Per-launch durations: the time between a launch's two HIP events brackets a few us more than the kernel (dispatch of the
+    # kernel after the first event, completion signalling before the second).  That overhead is measured live (the same pair
+    # around an EMPTY kernel, median of 64) and removed, leaving the empty kernel 2 us of its own so that the correction stays
+    # on the conservative side of rocprofv3's kernel durations (profiles/r03_train_step_profiled_leg.txt: 34.2 us per launch
+    # of the dominant class where this gives 35.0 and the raw events 38.9).  The raw figures are reported beside it.
+    over_ms = max(0.0, bracket_ms - 0.002)
+    for v in prof.values():
+        v["ms_raw"] = v["ms"]
+        v["ms"] = max(0.0, v["ms"] - over_ms * v["launches"])
     dom = max(prof, key=lambda k: prof[k]["ms"])
     d = prof[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    achieved_raw = d["flops"] / (d["ms_raw"] * 1e-3) / 1e12 if d["ms_raw"] > 0 else 0.0
     step_flops = 3 * FWD_FLOPS_PER_IMAGE_64 * args.batch * (args.res / 64) ** 2
     step_ms = 1e3 * dt / args.steps
     out = {
@@ -523,9 +535,12 @@ def main():
                      "algorithmic_bytes_per_launch": d["bytes"] / max(1, d["launches"]),
                      "hbm_GBps_algorithmic": d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0,
                      "launches": d["launches"], "avg_launch_ms": d["ms"] / max(1, d["launches"]),
-                     "measured_over": "%d steps (%.2f ms/step) with HIP event pairs around every contraction launch, run right "
-                                      "after the timed region with the weight-gradient side stream off so that each launch "
-                                      "has the chip to itself (timed region: side stream %s, hipGraph %s)"
+                     "event_bracket_ms": bracket_ms, "avg_launch_ms_raw_events": d["ms_raw"] / max(1, d["launches"]),
+                     "achieved_raw_events": achieved_raw, "frac_raw_events": achieved_raw / PEAK_FP32_MFMA_TFLOPS,
+                     "measured_over": "%d steps (%.2f ms/step) with HIP event pairs around every contraction launch, minus the pair's "
+                                      "own overhead (event_bracket_ms - 2 us, measured around an empty kernel; *_raw_events = without "
+                                      "that correction), run right after the timed region with the weight-gradient side stream off "
+                                      "so that each launch has the chip to itself (timed region: side stream %s, hipGraph %s)"
                                       % (prof_steps, 1e3 * dt_prof / prof_steps, "on" if side_was else "off", bool(graphed)),
                      "by_class": {k: {"ms_per_step": v["ms"] / prof_steps, "launches_per_step": v["launches"] / prof_steps,
                                       "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0,

@@ -80,6 +80,10 @@ int sdm_plan_free(int handle);
 #define SDM_PROF_CLASSES 7
 int sdm_prof_begin(int capacity);
 int sdm_prof_end(double* ms, long long* launches, double* flops, double* bytes);
+/* Median elapsed time (ms) of an event pair around an EMPTY kernel, `reps` launches on the stream (which is synchronised): what
+ * the per-launch timing above adds to a kernel's own duration, plus the empty kernel's own ~1-2 us.  bench.py reports it and a
+ * kernel-only estimate next to the raw event figures (rocprofv3's kernel durations are the reference for that estimate). */
+double sdm_prof_bracket_ms(int reps, sdm_stream_t s);
 
 /* A logical matrix of "pixel rows x channels", optionally the channel-concat of two
  * tensors (U_Net.py:168 torch.cat) and optionally carrying a pending per-(image,channel)

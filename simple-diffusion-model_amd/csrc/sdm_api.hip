@@ -33,6 +33,7 @@ extern "C" int sdm_device_info(int* out4) {
 }
 
 // ---- launch plans -------------------------------------------------------------------------------------------------
+#include <algorithm>
 #include <vector>
 namespace {
 struct PlanRec { const void* fn; dim3 grid, block; unsigned lds; int nargs; size_t blob_off; unsigned arg_off[32]; };
@@ -194,6 +195,30 @@ extern "C" int sdm_prof_begin(int capacity) {
   g_prof_cap = capacity;
   g_prof_armed = true;
   return SDM_OK;
+}
+
+// What an event pair adds to the launch it brackets: the same pair around an EMPTY kernel, median of `reps` launches on the
+// given stream (the stream is synchronised).  The result still contains the empty kernel's own ~1-2 us.
+__global__ void sdm_prof_null_kernel() {}
+extern "C" double sdm_prof_bracket_ms(int reps, sdm_stream_t s) {
+  if (reps < 1) reps = 1;
+  if (reps > 1024) reps = 1024;
+  hipStream_t st = (hipStream_t)s;
+  std::vector<hipEvent_t> ev(2 * (size_t)reps);
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) return -1.0;
+  for (int i = 0; i < 8; ++i) sdm_prof_null_kernel<<<dim3(1), dim3(64), 0, st>>>();
+  for (int i = 0; i < reps; ++i) {
+    (void)hipEventRecord(ev[2 * i], st);
+    sdm_prof_null_kernel<<<dim3(1), dim3(64), 0, st>>>();
+    (void)hipEventRecord(ev[2 * i + 1], st);
+  }
+  (void)hipStreamSynchronize(st);
+  std::vector<float> t((size_t)reps, 0.f);
+  for (int i = 0; i < reps; ++i) (void)hipEventElapsedTime(&t[i], ev[2 * i], ev[2 * i + 1]);
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  std::sort(t.begin(), t.end());
+  return (double)t[reps / 2];
 }
 
 extern "C" int sdm_prof_end(double* ms, long long* launches, double* flops, double* bytes) {

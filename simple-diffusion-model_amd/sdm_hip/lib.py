@@ -92,6 +92,7 @@ _PROTOS = {
     "sdm_plan_run": (_i, [_i, _i, fp]),
     "sdm_plan_free": (_i, [_i]),
     "sdm_prof_begin": (_i, [_i]),
+    "sdm_prof_bracket_ms": (C.c_double, [_i, fp]),
     "sdm_prof_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sdm_igemm": (_i, [C.POINTER(IgemmDesc), fp]),
     "sdm_igemm_workspace_bytes": (_sz, [C.POINTER(IgemmDesc)]),
@@ -214,6 +215,12 @@ PROF_CLASSES = ("igemm_128x128", "igemm_64x64", "igemm_32x128", "wgrad_128x128",
 
 def prof_begin(capacity=100000):
     call("sdm_prof_begin", capacity)
+
+
+def prof_bracket_ms(stream, reps=64):
+    """Median time between the two events around an EMPTY kernel on ``stream`` (raw stream handle): the per-launch timing's
+    own overhead plus the empty kernel's ~1-2 us."""
+    return float(_lib.sdm_prof_bracket_ms(int(reps), stream))
 
 
 def prof_end():
