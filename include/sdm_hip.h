@@ -34,6 +34,7 @@ typedef void* sdm_stream_t; /* hipStream_t */
 #define SDM_ERR_ARG (-1)
 #define SDM_ERR_LAUNCH (-2)
 #define SDM_ERR_UNSUPPORTED (-3)
+#define SDM_ERR_DEVICE (-4)      /* a kernel reported a failure (a bounded device-side wait gave up); see sdm_device_error_poll */
 
 #define SDM_ACT_NONE 0
 #define SDM_ACT_SILU 1
@@ -57,6 +58,15 @@ int sdm_stream_order(sdm_stream_t from, sdm_stream_t to);
  * including finishing passes; memsets and the caller's own torch kernels are not included).  bench.py reports the
  * difference over one step as launches_per_step. */
 unsigned long long sdm_launch_count(void);
+/* Device-side failure word.  The cooperative kernels (sdm_gn_apply_coop, sdm_gn_bwd_coop) bound every inter-workgroup
+ * wait; a wait that gives up writes NaN outputs, leaves the exchange state zero and stores a code in a host-mapped word.
+ * sdm_device_error_init allocates that word (idempotent; hipHostMalloc: call it once, outside stream capture, before the
+ * first launch -- without it the kernels are still bounded and still write NaN, but nothing reports).  From then on EVERY
+ * launch function of the library checks the word after enqueueing its kernels (a read of pinned host memory, no
+ * synchronisation) and returns SDM_ERR_DEVICE with the failing kernel named in sdm_last_error(); sdm_device_error_poll
+ * does the same check on its own (after a stream synchronisation it is exact).  The word is cleared by the report. */
+int sdm_device_error_init(void);
+int sdm_device_error_poll(void);
 
 /* Launch plans: record the library's kernel launches once, replay them from C (SURVEY 8b "who calls the C ABI": the
  * samplers' captured step; VERDICT r2 "C-side launch plan").  Between sdm_plan_begin and sdm_plan_end every launch the

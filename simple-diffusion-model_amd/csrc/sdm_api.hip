@@ -13,7 +13,44 @@ int sdm_set_error(int code, const char* fmt, ...) {
 
 unsigned long long g_sdm_launches = 0;
 
-extern "C" int sdm_version(void) { return 300; }
+extern "C" int sdm_version(void) { return 400; }
+
+// ---- device-side failure word -------------------------------------------------------------------------------------
+volatile unsigned* g_sdm_errw_host = nullptr;
+unsigned* g_sdm_errw_dev = nullptr;
+
+static const char* deverr_text(unsigned code) {
+  switch (code) {
+    case SDM_DEVERR_GN_COOP_TIMEOUT: return "sdm_gn_apply_coop: a slab gave up waiting for the other slabs of its image (outputs are NaN)";
+    case SDM_DEVERR_GN_BWD_COOP_TIMEOUT: return "sdm_gn_bwd_coop: a slab gave up waiting for the other slabs of its image (outputs are NaN)";
+    case SDM_DEVERR_DP_TIMEOUT: return "sdm_dp: a device-side wait gave up";
+    default: return "unknown device-side failure";
+  }
+}
+int sdm_report_device_error(const char* where) {
+  const unsigned code = *g_sdm_errw_host;
+  *g_sdm_errw_host = 0;                      // reported once
+  return sdm_set_error(SDM_ERR_DEVICE, "device-side failure %u seen at %s: %s", code, where, deverr_text(code));
+}
+// Allocates the word (idempotent).  Must run outside stream capture (hipHostMalloc); the host language calls it once per
+// process before its first launch.
+extern "C" int sdm_device_error_init(void) {
+  if (g_sdm_errw_host) return SDM_OK;
+  void* h = nullptr;
+  if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return sdm_set_error(SDM_ERR_LAUNCH, "device_error_init: hipHostMalloc failed");
+  memset(h, 0, 64);
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return sdm_set_error(SDM_ERR_LAUNCH, "device_error_init: no device pointer"); }
+  g_sdm_errw_dev = (unsigned*)d;
+  g_sdm_errw_host = (volatile unsigned*)h;
+  return SDM_OK;
+}
+// 0, or SDM_ERR_DEVICE (sdm_last_error names the kernel) when a kernel has reported a failure since the last report.
+// Does not synchronise: call it after a synchronisation point to be sure that everything enqueued has been looked at.
+extern "C" int sdm_device_error_poll(void) {
+  if (g_sdm_errw_host && *g_sdm_errw_host) return sdm_report_device_error("sdm_device_error_poll");
+  return SDM_OK;
+}
 
 extern "C" unsigned long long sdm_launch_count(void) { return g_sdm_launches; }
 

@@ -32,11 +32,23 @@ void sdm_plan_taint(const char* why);
 
 extern unsigned long long g_sdm_launches;   // kernel launches issued by the library (sdm_launch_count)
 
+// Device-side failure word (sdm_device_error_init): one host-mapped, pinned 32-bit word.  A kernel whose bounded spin gave
+// up stores a non-zero code there with a system-scope atomic; every later launch function of the library sees it on the
+// host WITHOUT synchronising (a plain volatile read of pinned memory) and returns SDM_ERR_DEVICE through the ordinary
+// error convention.  Null until sdm_device_error_init has run (kernels then skip the store).
+extern volatile unsigned* g_sdm_errw_host;
+extern unsigned* g_sdm_errw_dev;
+int sdm_report_device_error(const char* where);
+#define SDM_DEVERR_GN_COOP_TIMEOUT 1u
+#define SDM_DEVERR_GN_BWD_COOP_TIMEOUT 2u
+#define SDM_DEVERR_DP_TIMEOUT 3u
+
 #define SDM_CHECK_LAUNCH(name)                                                         \
   do {                                                                                 \
     ++g_sdm_launches;                                                                  \
     hipError_t e_ = hipGetLastError();                                                 \
     if (e_ != hipSuccess) return sdm_set_error(SDM_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+    if (g_sdm_errw_host && *g_sdm_errw_host) return sdm_report_device_error(name);     \
   } while (0)
 
 #define SDM_MEMSET0(ptr, bytes, st)                                              \

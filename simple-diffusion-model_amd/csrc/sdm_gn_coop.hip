@@ -10,10 +10,14 @@
 //   -> one lane polls arrive[image] (agent-scope relaxed loads, s_sleep) until every slab of the image has arrived
 //   -> the sums are read back with agent-scope atomic loads (8-byte atomics on both sides: no cache holds them)
 //   -> apply from registers, store; the last slab to DEPART zeroes the sums and both counters for the next launch.
-// Placement-independent: nothing depends on which CU / XCD a slab runs on.  Residency: the grid is at most 256 workgroups
-// of 1024 threads (the host refuses anything larger, and falls back to the one-workgroup-per-group kernel), i.e. at most
-// half of what the chip holds, and an image's slabs are consecutive block ids; a poll therefore always ends -- at worst
-// after kernels of other streams have drained.
+// Placement-independent: nothing depends on which CU / XCD a slab runs on.  Residency: the host sizes the grid against the
+// occupancy query (half of occupancy x CU count of THIS device; anything larger is declined and the caller runs the
+// one-workgroup-per-group kernel), and an image's slabs are consecutive block ids, so on an otherwise idle device every slab is
+// resident and the poll ends.  That argument is per grid, not per device -- two cooperative launches on two streams can each
+// hold part of their slabs resident -- so EVERY poll is bounded: it gives up after `timeout` ticks of the 100 MHz
+// s_memrealtime clock (2 s by default; legitimate waits are kernels of other streams draining, i.e. milliseconds).  A slab
+// that gave up writes NaN instead of results, reports SDM_DEVERR_* through the host-mapped failure word
+// (sdm_device_error_init) and still departs, so the last slab leaves the exchange state zero as after a good launch.
 #include <stdlib.h>
 
 #include "sdm_common.h"
@@ -31,12 +35,26 @@ struct GnCoopArgs {
   int slab_rows, lc4, lq4;       // rows per slab; log2(C/4); log2(channel quads per group)
   double* sums;                  // [images][GC_MAXG][2], zero between launches
   unsigned* ctr;                 // [images][2] arrive / depart, zero between launches
+  unsigned* errw;                // host-mapped failure word (may be null)
+  unsigned long long timeout;    // s_memrealtime ticks (100 MHz) a slab waits for the others
+  unsigned expect_extra;         // test hook: arrivals expected beyond the grid's slabs (forces the give-up path)
 };
+
+// One lane waits until *ctr >= need; false when `timeout` ticks passed first.  Relaxed agent-scope loads (never cached).
+__device__ __forceinline__ bool gc_wait_arrivals(unsigned* ctr, unsigned need, unsigned long long timeout) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
 
 template <bool BF>
 __global__ __launch_bounds__(GC_T) void gn_apply_coop_kernel(const GnCoopArgs a) {
   __shared__ double ls[2][GC_MAXG];
   __shared__ float st[2][GC_MAXG];
+  __shared__ int s_ok;
   const int tid = threadIdx.x, lane = tid & 63;
   const int n = blockIdx.y, nsl = gridDim.x;
   const int C4 = a.C >> 2, q4 = 1 << a.lq4;
@@ -104,9 +122,12 @@ __global__ __launch_bounds__(GC_T) void gn_apply_coop_kernel(const GnCoopArgs a)
   __syncthreads();
   if (tid == 0) {
     __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nsl) __builtin_amdgcn_s_sleep(2);
+    const bool ok = gc_wait_arrivals(ctr, (unsigned)nsl + a.expect_extra, a.timeout);
+    if (!ok && a.errw) __hip_atomic_store(a.errw, SDM_DEVERR_GN_COOP_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    s_ok = ok;
   }
   __syncthreads();
+  const bool ok = s_ok != 0;
   if (tid < a.groups) {
     const double s1 = __hip_atomic_load(gs + tid * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double s2 = __hip_atomic_load(gs + tid * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -142,7 +163,7 @@ __global__ __launch_bounds__(GC_T) void gn_apply_coop_kernel(const GnCoopArgs a)
     const long long row = row0 + r;
     f32x4 o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = v[k][i] * sc[i] + sh[i];
+    for (int i = 0; i < 4; ++i) o[i] = ok ? v[k][i] * sc[i] + sh[i] : __builtin_nanf("");     // a failed exchange is visible
     if (a.x0) {
       if (BF) {
         const u16x4 u = (c < a.csplit) ? *(const u16x4*)((const bf16_t*)a.x0 + row * a.ldx0 + c)
@@ -183,6 +204,34 @@ static int ilog2x(long v) {
   return l;
 }
 
+// Workgroups of `kern` (T threads, its static LDS) that are resident together on the CURRENT device, halved for margin:
+// occupancy query x CU count / 2, additionally limited by the 32 waves a CU holds.  Cached per (kernel, device).
+static int gc_resident_cap(const void* kern, int T, int slot) {
+  static int cache[8][16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  if (cache[slot][dev] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, T, 0) != hipSuccess) per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    const int by_waves = 2048 / T;
+    if (per_cu > by_waves) per_cu = by_waves;
+    cache[slot][dev] = per_cu > 0 && cus > 0 ? (per_cu * cus) / 2 : -1;
+  }
+  return cache[slot][dev] > 0 ? cache[slot][dev] : 0;
+}
+// bound of every inter-slab wait, in 100 MHz ticks (default 2 s; SDM_GN_COOP_TIMEOUT_MS overrides), and the test hook
+// SDM_GN_COOP_TEST_EXTRA=n (a slab then expects n arrivals that never come: the give-up path, bounded by the timeout)
+static unsigned long long gc_timeout_ticks() {
+  const char* e = getenv("SDM_GN_COOP_TIMEOUT_MS");
+  const double ms = e ? atof(e) : 2000.0;
+  return (unsigned long long)((ms > 0.0 ? ms : 2000.0) * 1e5);
+}
+static unsigned gc_expect_extra() {
+  const char* e = getenv("SDM_GN_COOP_TEST_EXTRA");
+  return e ? (unsigned)atoi(e) : 0u;
+}
+
 #define GC_MAX_IMAGES 256
 extern "C" size_t sdm_gn_apply_coop_state_bytes(void) {
   return (size_t)GC_MAX_IMAGES * GC_MAXG * 2 * sizeof(double) + (size_t)GC_MAX_IMAGES * 2 * sizeof(unsigned);
@@ -199,8 +248,11 @@ extern "C" int sdm_gn_apply_coop(const void* src, int64_t ld_src, int src_raw, f
   const int cpg = C / groups;
   const int lc4 = ilog2x(C / 4), lq4 = cpg % 4 == 0 ? ilog2x(cpg / 4) : -1;
   // applicability (else the caller runs the one-workgroup-per-group kernel): power-of-two quads per row and per group, a
-  // row no wider than the workgroup, at least two slabs per image and at most 256 workgroups in all
-  if (C % 4 != 0 || lc4 < 0 || lq4 < 0 || (C / 4) > GC_T || groups > GC_MAXG || images > GC_MAX_IMAGES) return SDM_NOT_APPLICABLE;
+  // group's quads inside one wave (the shuffle reduction), a row no wider than the workgroup, at least two slabs per image
+  // and no more workgroups than half of what this device keeps resident
+  if (C % 4 != 0 || lc4 < 0 || lq4 < 0 || (cpg / 4) > 64 || (C / 4) > GC_T || groups > GC_MAXG || images > GC_MAX_IMAGES)
+    return SDM_NOT_APPLICABLE;
+  const int cap = gc_resident_cap(bf16 ? (const void*)gn_apply_coop_kernel<true> : (const void*)gn_apply_coop_kernel<false>, GC_T, bf16 ? 1 : 0);
   const long long quads = (long long)HW * (C / 4);
   long long nsl = 1;
   while (nsl * GC_T * GC_MAXV < quads) nsl <<= 1;
@@ -209,7 +261,7 @@ extern "C" int sdm_gn_apply_coop(const void* src, int64_t ld_src, int src_raw, f
   // so it is used from 32 slabs per image on -- the 64x64 maps -- and declined below (SDM_GN_COOP_MIN_SLABS overrides).
   static const char* ms = getenv("SDM_GN_COOP_MIN_SLABS");
   const long long min_slabs = ms ? atoll(ms) : 32;
-  if (nsl < 2 || nsl < min_slabs || nsl * images > 256) return SDM_NOT_APPLICABLE;
+  if (nsl < 2 || nsl < min_slabs || nsl * images > cap) return SDM_NOT_APPLICABLE;
   const int slab_rows = (int)((HW + nsl - 1) / nsl);
   if ((long long)slab_rows * (C / 4) > (long long)GC_T * GC_MAXV) return SDM_NOT_APPLICABLE;
   const size_t esz = bf16 ? 2 : 4;
@@ -228,6 +280,7 @@ extern "C" int sdm_gn_apply_coop(const void* src, int64_t ld_src, int src_raw, f
   a.slab_rows = slab_rows; a.lc4 = lc4; a.lq4 = lq4;
   a.sums = (double*)state;
   a.ctr = (unsigned*)((char*)state + (size_t)GC_MAX_IMAGES * GC_MAXG * 2 * sizeof(double));
+  a.errw = g_sdm_errw_dev; a.timeout = gc_timeout_ticks(); a.expect_extra = gc_expect_extra();
   dim3 grid((unsigned)nsl, images);
   if (bf16) SDM_LAUNCH(gn_apply_coop_kernel<true>, grid, dim3(GC_T), 0, (hipStream_t)s, a);
   else SDM_LAUNCH(gn_apply_coop_kernel<false>, grid, dim3(GC_T), 0, (hipStream_t)s, a);
@@ -260,6 +313,7 @@ struct GnBwdCoopArgs {
   float* ws;                     // [images][C][2], zero between launches
   int slab_rows, lc4, lq4;
   double* sums; unsigned* ctr;   // the forward kernel's exchange state
+  unsigned* errw; unsigned long long timeout; unsigned expect_extra;     // as in GnCoopArgs
 };
 
 template <bool BF>
@@ -280,6 +334,7 @@ __global__ __launch_bounds__(T) void gn_bwd_coop_kernel(const GnBwdCoopArgs a) {
   __shared__ double lg[2][GC_MAXG];      // single-slab images: the group pair without the trip through memory
   __shared__ float st[2][GC_MAXG];       // k1, k2 per group
   __shared__ int s_last;
+  __shared__ int s_ok;
   const int tid = threadIdx.x, lane = tid & 63;
   const int n = blockIdx.y, nsl = gridDim.x;
   const int C4 = a.C >> 2;
@@ -352,13 +407,17 @@ __global__ __launch_bounds__(T) void gn_bwd_coop_kernel(const GnBwdCoopArgs a) {
   }
   if (nsl > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (tid == 0) s_ok = 1;
   if (nsl > 1) {
     if (tid == 0) {
       __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nsl) __builtin_amdgcn_s_sleep(2);
+      const bool okw = gc_wait_arrivals(ctr, (unsigned)nsl + a.expect_extra, a.timeout);
+      if (!okw && a.errw) __hip_atomic_store(a.errw, SDM_DEVERR_GN_BWD_COOP_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      s_ok = okw;
     }
-    __syncthreads();
   }
+  __syncthreads();
+  const bool ok = s_ok != 0;
   if (tid < a.groups) {
     double P, Q;
     if (nsl > 1) {
@@ -397,6 +456,7 @@ __global__ __launch_bounds__(T) void gn_bwd_coop_kernel(const GnBwdCoopArgs a) {
       for (int i = 0; i < 4; ++i) {
         v[i] = k0[i] * d[k][i] + k1 * yv[k][i] + k2;
         if (a.z) v[i] *= sdm_dsilu(zv[k][i]);
+        if (!ok) v[i] = __builtin_nanf("");
       }
       const long long idx = (row0 + r) * a.lddz + c;
       if (BF) {
@@ -468,7 +528,9 @@ extern "C" int sdm_gn_bwd_coop(const void* dout, int64_t lddo, const void* y, in
   const long long quads = (long long)HW * (C / 4);
   long long nsl = 1;
   while (nsl * T * GC_MAXV < quads) nsl <<= 1;
-  if (nsl * images > (T == 1024 ? 256 : 1024)) return SDM_NOT_APPLICABLE;     // all resident at once: 4 small workgroups per CU at most
+  const void* kfn = T == 1024 ? (bf16 ? (const void*)gn_bwd_coop_kernel<true, 1024> : (const void*)gn_bwd_coop_kernel<false, 1024>)
+                              : (bf16 ? (const void*)gn_bwd_coop_kernel<true, 256> : (const void*)gn_bwd_coop_kernel<false, 256>);
+  if (nsl * images > gc_resident_cap(kfn, T, 2 + (T == 1024 ? 2 : 0) + (bf16 ? 1 : 0))) return SDM_NOT_APPLICABLE;     // all resident at once
   const int slab_rows = (int)((HW + nsl - 1) / nsl);
   if ((long long)slab_rows * (C / 4) > (long long)T * GC_MAXV) return SDM_NOT_APPLICABLE;
   const size_t esz = bf16 ? 2 : 4;
@@ -486,6 +548,7 @@ extern "C" int sdm_gn_bwd_coop(const void* dout, int64_t lddo, const void* y, in
   a.slab_rows = slab_rows; a.lc4 = lc4; a.lq4 = lq4;
   a.sums = (double*)state;
   a.ctr = (unsigned*)((char*)state + (size_t)GC_MAX_IMAGES * GC_MAXG * 2 * sizeof(double));
+  a.errw = g_sdm_errw_dev; a.timeout = gc_timeout_ticks(); a.expect_extra = gc_expect_extra();
   dim3 grid((unsigned)nsl, images);
   if (T == 1024) {
     if (bf16) SDM_LAUNCH((gn_bwd_coop_kernel<true, 1024>), grid, dim3(1024), 0, (hipStream_t)s, a);

@@ -107,6 +107,8 @@ _PROTOS = {
     "sdm_gn_affine": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, fp, fp, fp, fp]),
     "sdm_gn_apply_fused": (_i, [fp, _i64, _i, _f, fp, _i, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, fp]),
     "sdm_gn_apply_coop_state_bytes": (_sz, []),
+    "sdm_device_error_init": (_i, []),
+    "sdm_device_error_poll": (_i, []),
     "sdm_gn_apply_coop": (_i, [fp, _i64, _i, _f, fp, _i, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, _i, fp, _sz,
                               fp]),
     "sdm_gn_bwd_coop": (_i, [fp, _i64, fp, _i64, fp, _i64, _i, _i, _i, _i, fp, fp, fp, _i, fp, fp, fp, _i64, fp, fp, fp, fp, _i, fp,
@@ -200,6 +202,22 @@ def call(name, *args):
 
 def raw(name):
     return getattr(_lib, name)
+
+
+_DEVERR_READY = [False]
+
+
+def device_error_init():
+    """Allocate the host-mapped failure word the bounded device-side waits report through (once per process; must happen
+    outside stream capture, so ops calls it before the first launch of a process)."""
+    if not _DEVERR_READY[0]:
+        call("sdm_device_error_init")
+        _DEVERR_READY[0] = True
+
+
+def check_device_error():
+    """Raise SdmError if a kernel has reported a failure (exact after a stream synchronisation)."""
+    call("sdm_device_error_poll")
 
 
 def version():

@@ -139,6 +139,29 @@ class _SideStream:
 SIDE = _SideStream()
 
 
+class _StreamKeyed:
+    """Library-owned device state that ONE stream may use at a time (zero-filled scratch, the cooperative GroupNorm's
+    exchange words): one instance per (device, stream that launches go to) outside graph capture, one per capture_scope
+    inside -- so two forwards running concurrently on two streams of a process, or a replaying graph beside eager
+    launches, never meet in the same words.  A capture's instances are made when the scope is entered (allocation is not
+    possible once the capture runs), sized like the largest instance the warm-up run left on the device."""
+    _all = []
+
+    def __init__(self):
+        self.by_stream = {}
+        _StreamKeyed._all.append(self)
+
+    def _prealloc(self, device_index):
+        """Tensor for a capture that is about to start on ``device_index`` (None: nothing to pre-size from)."""
+        raise NotImplementedError
+
+    def _slot(self, device):
+        scope = capture_scope.current()
+        if scope is not None:
+            return scope.local, (id(self), device.index)
+        return self.by_stream, (device.index, _stream())
+
+
 class capture_scope:
     """Lifetime of the library-owned buffers a captured hipGraph points at.
 
@@ -150,11 +173,25 @@ class capture_scope:
     captures a graph opens a scope; every cache that hands out a buffer during the capture registers it with keep(); the
     scope's list is stored next to the graph and dies with it.  The caches themselves can then be bounded (LRU) without
     ever freeing what a live graph still needs."""
+    The scope also OWNS the single-stream state of the capture (_StreamKeyed): the graph's launches use buffers of their
+    own, made here, before the capture starts."""
     _stack = []
+
+    @staticmethod
+    def current():
+        return capture_scope._stack[-1] if capture_scope._stack else None
 
     def __enter__(self):
         self.kept = []
-        capture_scope._stack.append(self.kept)
+        self.local = {}
+        if torch.cuda.is_available():
+            dev = torch.cuda.current_device()
+            for owner in _StreamKeyed._all:
+                t = owner._prealloc(dev)
+                if t is not None:
+                    self.local[(id(owner), dev)] = t
+                    self.kept.append(t)
+        capture_scope._stack.append(self)
         return self.kept
 
     def __exit__(self, *exc):
@@ -165,27 +202,35 @@ class capture_scope:
 def keep(obj):
     """Register ``obj`` with the graph capture in progress (no-op outside a capture_scope)."""
     if capture_scope._stack and obj is not None:
-        capture_scope._stack[-1].append(obj)
+        capture_scope._stack[-1].kept.append(obj)
 
 
-class _Workspace:
+def _all_zero(owner):
+    """True when every buffer of a _StreamKeyed owner is zero (tests of the zero-filled contract)."""
+    return all(float(b.abs().max()) == 0.0 for b in owner.by_stream.values() if b.numel())
+
+
+class _Workspace(_StreamKeyed):
     """Zero-filled scratch (split-K partial sums, GroupNorm-backward channel sums), grown on demand; the kernels leave
-    what they touched zero-filled again.  An outgrown buffer is dropped: a captured hipGraph that still points at it
-    holds its own reference (capture_scope)."""
+    what they touched zero-filled again.  One buffer per launching stream (_StreamKeyed).  An outgrown buffer is dropped: a
+    captured hipGraph that still points at it holds its own reference (capture_scope)."""
 
-    def __init__(self):
-        self.buf = None
+    def _prealloc(self, device_index):
+        n = max((b.numel() for (d, _), b in self.by_stream.items() if d == device_index), default=0)
+        return torch.zeros(n, dtype=torch.float32, device=torch.device("cuda", device_index)) if n else None
 
     def get(self, nbytes, device):
         if nbytes == 0:
             return None
-        if self.buf is None or self.buf.numel() * 4 < nbytes or self.buf.device != device:
+        store, key = self._slot(device)
+        buf = store.get(key)
+        if buf is None or buf.numel() * 4 < nbytes:
             if torch.cuda.is_current_stream_capturing():
                 raise lib.SdmError("zero-filled scratch (split-K / GroupNorm backward) must be sized by a warm-up call before "
                                    "graph capture")
-            self.buf = torch.zeros((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)   # zero-filled contract
-        keep(self.buf)
-        return self.buf
+            buf = store[key] = torch.zeros((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)   # zero-filled contract
+        keep(buf)
+        return buf
 
 
 WS = _Workspace()
@@ -238,14 +283,18 @@ def _launch_igemm(d, device, bf16=False, out_f32=False):
     ws = WS.get(need, device)
     d.ws = _p(ws)
     d.ws_bytes = ws.numel() * 4 if ws is not None else 0
+    _LAST_WS[0] = ws
     if bf16:
         return lib.call("sdm_igemm_bf16", C.byref(d), int(out_f32), _stream())
     return lib.call("sdm_igemm", C.byref(d), _stream())
 
 
+_LAST_WS = [None]       # the scratch the last contraction launch was given (a Deferred output lives there)
+
+
 class Deferred:
     """A conv output whose split-K finishing pass has NOT run: raw sums [rows, c] in the shared zero-filled scratch
-    (WS.buf), plus what the finishing pass would have applied.  Consumed -- and the scratch cleared -- by the very next
+    (the launching stream's WS buffer), plus what the finishing pass would have applied.  Consumed -- and the scratch cleared -- by the very next
     launch (gn_apply_fused); nothing else may touch WS in between."""
     __slots__ = ("ws", "n", "h", "w", "c", "bias", "act", "dtype", "out", "z")
 
@@ -352,7 +401,7 @@ def conv_fwd(x, wt, bias, kind, act=ACT_SILU, save_z=False, defer=False, gn_stat
         d.gn_sums = _p(sums)
     rc = _launch_igemm(d, wt.device, bf16=bf)
     if rc == lib.DEFERRED:
-        return Deferred(WS.buf, x.n, ho, wo, cout, bias, act, BF16 if bf else torch.float32, out=out if save_z else None, z=z)
+        return Deferred(_LAST_WS[0], x.n, ho, wo, cout, bias, act, BF16 if bf else torch.float32, out=out if save_z else None, z=z)
     y = Act(out, x.n, ho, wo, z=z)
     if rc == lib.STATS_DONE:
         y.stats = sums
@@ -887,18 +936,35 @@ GN_COOP = [os.environ.get("SDM_GN_COOP", "1") != "0"]
 # small kernels (7.2 -> 7.45 ms): its slabs must all be resident before any can finish, and the weight-gradient stream
 # keeps the CUs full, so the big maps wait 118 us where the three kernels take 69; the small maps tie (17 vs 15 us).
 GN_COOP_BWD = [os.environ.get("SDM_GN_COOP_BWD", "0") == "1"]
-_GN_COOP_STATE = {}
+class _GnCoopState(_StreamKeyed):
+    """Exchange state of sdm_gn_apply_coop / sdm_gn_bwd_coop (group sums + arrival counters; zero between launches): one per
+    (device, launching stream), one per captured graph -- two concurrent users never share sums or counters."""
+
+    def _new(self, device):
+        lib.device_error_init()          # the bounded waits of those kernels report through the failure word
+        return torch.zeros(lib.raw("sdm_gn_apply_coop_state_bytes")(), dtype=torch.uint8, device=device)
+
+    def _prealloc(self, device_index):
+        if not any(d == device_index for (d, _) in self.by_stream):
+            return None
+        return self._new(torch.device("cuda", device_index))
+
+    def get(self, device):
+        store, key = self._slot(device)
+        st = store.get(key)
+        if st is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise lib.SdmError("sdm_gn_apply_coop state must be created by a warm-up call before graph capture")
+            st = store[key] = self._new(device)
+        keep(st)
+        return st
+
+
+_GN_COOP_STATE = _GnCoopState()
 
 
 def _gn_coop_state(device):
-    """Exchange state of sdm_gn_apply_coop (zero between launches; one per device, used on the forward's stream only)."""
-    st = _GN_COOP_STATE.get(device)
-    if st is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise lib.SdmError("sdm_gn_apply_coop state must be created by a warm-up call before graph capture")
-        st = _GN_COOP_STATE[device] = torch.zeros(lib.raw("sdm_gn_apply_coop_state_bytes")(), dtype=torch.uint8, device=device)
-    keep(st)
-    return st
+    return _GN_COOP_STATE.get(device)
 
 
 def gn_apply_fused(y, gamma, beta, mod, groups=32, eps=1e-5, residual=None, train=False):
