@@ -155,6 +155,158 @@ def seeded_params(cfg, seed=0, gain=1.0, dtype=torch.float32):
 
 
 # --------------------------------------------------------------------------- #
+# bf16 STORAGE mode (round 4): the same formulas with a round-to-nearest-even to bf16 exactly where the HIP path STORES bf16
+# and fp32 everywhere it keeps fp32.  The reference has no bf16 mode (its reduced-precision path is fp16 autocast,
+# train_diffusion.py:130,333, and holds no fixture), so this is not a pin of the rounding against the reference: it is
+# the reference's arithmetic (pinned above, storage=None reproduces every golden bit for bit) composed with a storage
+# model that is read off the HIP path's kernel boundaries:
+#   forward   conv / convT / token-linear weights: bf16 copies (sdm_cast_bf16; stem conv: fp32 weights and fp32 image);
+#             every contraction epilogue: fp32 accumulator -> alpha, bias -> activation -> (+ residual) -> bf16 store;
+#             GroupNorm statistics from the STORED (rounded) values, fp32 / fp64 sums; the folded AdaGN affine is applied
+#             by sdm_affine_residual_bf16 / the fused tails -> bf16 store; attention: qkv bf16, scores fp32, probabilities
+#             bf16 (not rounded at all in the short-sequence no-grad core, which never writes them), P.V -> bf16, output
+#             projection + residual -> bf16; head conv: bf16 weights, fp32 result; embedding MLPs, y_scale, samplers: fp32.
+#   backward  (training, sdm_bf16_train.hip) activation gradients are stored bf16 at: every conv pre-activation (the
+#             data-gradient epilogue multiplies by silu'(z) -- z being the STORED bf16 pre-activation -- adds the skip
+#             gradients and rounds once), the materialised AdaGN output, block outputs, qkv / attention result, dS of the
+#             column softmax, the two halves of a skip concat, the loss gradient entering the head conv; weight gradients,
+#             GroupNorm / modulation / embedding gradients are fp32 sums over those bf16 operands.
+# With the storage points equal, what is left between the HIP path and this mode is fp32 evaluation order in front of the
+# stores -- and that does NOT stay small through a network: see Bf16Storage (jitter / floor_twin) for why, and for the
+# derived gates (a multiple of the model's own flip-noise floor; the fp32-oracle gates stay as the outer bound).  One
+# storage stage at a time the agreement is at flip level: a net without GroupNorm / AdaGN (golden case no_emb), whose
+# stores are all fed by EXACT fp32 sums of bf16 products, reproduces this mode to 7e-8.
+# --------------------------------------------------------------------------- #
+def round_bf16(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _store(x, q):
+    """fp32 value -> what a bf16 store keeps.  q.jitter > 0 first moves the value by a relative jitter * U(-1, 1): a model
+    of fp32 evaluation-order noise (a few 2^-24) in FRONT of the rounding (see Bf16Storage.floor_twin)."""
+    if q is not None and q.jitter > 0.0:
+        x = x * (1.0 + q.jitter * (2.0 * torch.rand(x.shape, generator=q.gen) - 1.0))
+    return round_bf16(x)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """bf16 store of a value whose gradient stays fp32 (weight copies: dW is an fp32 sum; probabilities: dP is fp32)."""
+    @staticmethod
+    def forward(ctx, x, q):
+        return _store(x, q)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _RoundBoth(torch.autograd.Function):
+    """bf16 store of an activation AND of its gradient (a tensor that exists in HBM in both passes)."""
+    @staticmethod
+    def forward(ctx, x, q):
+        ctx.q = q
+        return _store(x, q)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _store(g, ctx.q), None
+
+
+class _RoundGrad(torch.autograd.Function):
+    """fp32 forward value whose gradient is stored bf16 (scores: dS; a skip half entering the concat; the head's input gradient)."""
+    @staticmethod
+    def forward(ctx, x, q):
+        ctx.q = q
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _store(g, ctx.q), None
+
+
+class _ActStore(torch.autograd.Function):
+    """Contraction epilogue with SiLU on bf16 rows: y = bf16(silu(z)) from the fp32 z; the backward multiplies by silu' of the
+    STORED bf16 pre-activation and stores the result (the producer's dz) in bf16."""
+    @staticmethod
+    def forward(ctx, z, q):
+        ctx.q = q
+        if q is not None and q.jitter > 0.0:
+            z = z * (1.0 + q.jitter * (2.0 * torch.rand(z.shape, generator=q.gen) - 1.0))
+        ctx.save_for_backward(round_bf16(z))
+        return round_bf16(z * torch.sigmoid(z))
+
+    @staticmethod
+    def backward(ctx, g):
+        (zb,) = ctx.saved_tensors
+        sg = torch.sigmoid(zb)
+        return _store(g * (sg * (1 + zb * (1 - sg))), ctx.q), None
+
+
+class _StemConv(torch.autograd.Function):
+    """in_layer.0 on the bf16 training path: fp32 image x fp32 weights forward (sdm_stem_conv_bf16); the weight gradient
+    contracts the bf16-rounded image rows (sdm_nchw_to_rows_bf16) with the bf16 dz."""
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x, w, b, padding=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gw = torch.nn.grad.conv2d_weight(round_bf16(x), w.shape, g, padding=1)
+        return None, gw, g.sum(dim=(0, 2, 3))
+
+
+class Bf16Storage:
+    """Storage model of the HIP bf16 paths (see the block comment above).  ``small_attn(n, heads, S, dk, train)`` -> True
+    where the HIP path runs its short-sequence attention core: in a no-grad forward that core never writes the
+    probabilities (no rounding of P).  The default mirrors sdm_hip/ops.py:_small_attn_ok (S <= 256, n*heads*S^2 <= 160k
+    score elements, and with P kept -- training -- S <= 64); tests assert that the constants agree.
+
+    jitter / seed: the FLOOR of any comparison with this model.  A bf16 store is a discontinuous function of the fp32 value
+    in front of it, and two correct implementations differ in that value by fp32 evaluation-order noise (GroupNorm
+    statistics, the folded affine, softmax sums: a few 2^-24 relative).  Where the value sits that close to a rounding
+    boundary the stored element differs by a whole bf16 ulp (2^-8), the next layer sees a perturbation ~1e-4 and flips
+    further roundings: after a handful of layers the two computations carry INDEPENDENT rounding noise (measured on the
+    golden nets: a jitter of 2^-24 already moves the output by half of the whole bf16-vs-fp32 distance, and the distance
+    saturates there: it does not shrink with the jitter).  So the distance of a correct bf16 implementation to this
+    model is not "summation-order noise x rounding count" ~ 1e-4; it is the distance between this model and its own
+    jittered twin, which the oracle can compute: floor_twin().  The tests gate the HIP path at a small multiple of that
+    floor, and two-sided on the size of its bf16 error (HIP vs fp32 against model vs fp32); single storage stages, where
+    nothing can cascade, are gated at flip level (tests/test_gpu_bf16.py)."""
+
+    def __init__(self, train=False, max_s=256, max_work=160 * 1024, keep_p_max_s=64, jitter=0.0, seed=0):
+        self.train, self.max_s, self.max_work, self.keep_p_max_s = train, max_s, max_work, keep_p_max_s
+        self.jitter = float(jitter)
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def floor_twin(self, seed=1, jitter=2.0 ** -22):
+        """The same storage model with fp32-order noise of `jitter` (default four fp32 ulps) in front of every store."""
+        return Bf16Storage(self.train, self.max_s, self.max_work, self.keep_p_max_s, jitter, seed)
+
+    def weight(self, w):
+        return _RoundFwd.apply(w, None)       # (a weight copy is a plain cast: no evaluation-order noise in front of it)
+
+    def prob(self, p):
+        return _RoundFwd.apply(p, self)
+
+    def both(self, x):
+        return _RoundBoth.apply(x, self)
+
+    def grad(self, x):
+        return _RoundGrad.apply(x, self)
+
+    def act_store(self, z):
+        return _ActStore.apply(z, self)
+
+    def p_is_rounded(self, n, heads, S, dk):
+        small = S <= self.max_s and dk % 16 == 0 and n * heads * S * S <= self.max_work
+        if small and self.train:
+            small = S <= self.keep_p_max_s
+        return self.train or not small      # the P-keeping forms store bf16 probabilities; only the no-grad small core does not
+
+
+# --------------------------------------------------------------------------- #
 # layers
 # --------------------------------------------------------------------------- #
 def silu(x):
@@ -189,67 +341,98 @@ def adagn(P, name, x, emb):
     return s * xg + s
 
 
-def conv_block(P, name, x, emb=None, act=True):
-    x = F.conv2d(x, P[name + ".conv_layer.0.weight"], P[name + ".conv_layer.0.bias"], padding=1)
-    if act:
-        x = silu(x)
+def conv_block(P, name, x, emb=None, act=True, Q=None, edge=None):
+    """Q: Bf16Storage or None (fp32, the reference's arithmetic).  edge: "stem" (fp32 weights and image) / "head" (fp32
+    result, its input gradient stored bf16) on bf16 rows."""
+    w, b = P[name + ".conv_layer.0.weight"], P[name + ".conv_layer.0.bias"]
+    if Q is None:
+        x = F.conv2d(x, w, b, padding=1)
+        if act:
+            x = silu(x)
+    elif edge == "stem":
+        x = Q.act_store(_StemConv.apply(x, w, b) if Q.train else F.conv2d(x, w, b, padding=1))
+    elif edge == "head":
+        return Q.grad(F.conv2d(x, Q.weight(w), b, padding=1))
+    else:
+        x = F.conv2d(x, Q.weight(w), b, padding=1)
+        x = Q.act_store(x) if act else Q.both(x)
     if emb is not None:
-        x = adagn(P, name + ".adagn", x, emb)
+        x = adagn(P, name + ".adagn", x, emb)      # statistics of the stored values; the caller stores the modulated tensor
     return x
 
 
-def res_block(P, name, x, emb):
-    y = conv_block(P, name + ".conv_block_1", x, emb)
-    y = conv_block(P, name + ".conv_block_2", y, emb)
-    return y + x
+def res_block(P, name, x, emb, Q=None):
+    y = conv_block(P, name + ".conv_block_1", x, emb, Q=Q)
+    if Q is not None and emb is not None:
+        y = Q.both(y)                              # sdm_affine_residual_bf16 materialises the affine ahead of the second conv
+    y = conv_block(P, name + ".conv_block_2", y, emb, Q=Q)
+    return y + x if Q is None else Q.both(y + x)
 
 
-def attention(P, name, x, heads, dk):
+def attention(P, name, x, heads, dk, Q=None):
     N, C, H, W = x.shape
     d = dk or C
     xs = x.reshape(N, C, H * W).transpose(1, 2)                    # [N,S,C]
-    qkv = F.linear(xs, P[name + ".projection.weight"], P[name + ".projection.bias"])
+    wp, wo = P[name + ".projection.weight"], P[name + ".output.weight"]
+    if Q is not None:
+        wp, wo = Q.weight(wp), Q.weight(wo)
+    qkv = F.linear(xs, wp, P[name + ".projection.bias"])
+    if Q is not None:
+        qkv = Q.both(qkv)
     qkv = qkv.reshape(N, H * W, heads, 3 * d)
     q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
     q, k, v = (z.permute(0, 2, 1, 3) for z in (q, k, v))           # [N,h,S,d]
     s = torch.matmul(q, k.transpose(-1, -2)) * d ** -0.5           # [N,h,i,j]
+    if Q is not None:
+        s = Q.grad(s)                                              # dS of the column softmax is stored bf16
     p = torch.softmax(s, dim=2)                                    # over queries i
+    if Q is not None and Q.p_is_rounded(N, heads, H * W, d):
+        p = Q.prob(p)                                              # bf16 probabilities; dP stays fp32
     o = torch.matmul(p, v).permute(0, 2, 1, 3).reshape(N, H * W, heads * d)
-    o = F.linear(o, P[name + ".output.weight"], P[name + ".output.bias"]) + xs
+    if Q is not None:
+        o = Q.both(o)
+    o = F.linear(o, wo, P[name + ".output.bias"]) + xs
+    if Q is not None:
+        o = Q.both(o)
     return o.transpose(1, 2).reshape(N, C, H, W)
 
 
-def unet_block(P, cfg, name, x, emb, use_attn, up):
+def unet_block(P, cfg, name, x, emb, use_attn, up, Q=None):
     for r in range(cfg["num_resnet_blocks"]):
-        x = res_block(P, f"{name}.res_layers.{r}", x, emb)
+        x = res_block(P, f"{name}.res_layers.{r}", x, emb, Q=Q)
         if use_attn:
-            x = attention(P, f"{name}.attn_layers.{r}", x, cfg["num_heads"], cfg["dim_per_head"])
+            x = attention(P, f"{name}.attn_layers.{r}", x, cfg["num_heads"], cfg["dim_per_head"], Q=Q)
     w, b = P[f"{name}.out_layer.conv_layer.0.weight"], P[f"{name}.out_layer.conv_layer.0.bias"]
+    if Q is not None:
+        w = Q.weight(w)
     if up:
         x = F.conv_transpose2d(x, w, b, stride=2, padding=1)
     else:
         x = F.conv2d(x, w, b, stride=2, padding=1)
-    return silu(x)
+    return silu(x) if Q is None else Q.act_store(x)
 
 
-def unet_forward(P, cfg, x, t=None, cond=None):
-    """models/U_Net.py:147-173."""
+def unet_forward(P, cfg, x, t=None, cond=None, storage=None):
+    """models/U_Net.py:147-173.  storage: None / torch.float32 = the reference's fp32 arithmetic; torch.bfloat16 or a
+    Bf16Storage = the bf16 storage model of the HIP path (inference unless Bf16Storage(train=True))."""
     cfg = full_cfg(cfg)
+    Q = None if storage in (None, torch.float32) else (storage if isinstance(storage, Bf16Storage) else Bf16Storage())
     L = cfg["num_layers"]
     emb = cond_embedding(P, cfg, t, cond) if cfg["time_dim"] is not None else None
-    x = conv_block(P, "in_layer.0", x)
-    x = conv_block(P, "in_layer.1", x)
+    x = conv_block(P, "in_layer.0", x, Q=Q, edge="stem")
+    x = conv_block(P, "in_layer.1", x, Q=Q)
     skips = []
     for k in range(L):
-        x = unet_block(P, cfg, f"down_layers.{k}", x, emb, k in cfg["attn_layers"], False)
+        x = unet_block(P, cfg, f"down_layers.{k}", x, emb, k in cfg["attn_layers"], False, Q=Q)
         skips.append(x)
-    x = conv_block(P, "middle_layer.0", x)
-    x = conv_block(P, "middle_layer.1", x)
+    x = conv_block(P, "middle_layer.0", x, Q=Q)
+    x = conv_block(P, "middle_layer.1", x, Q=Q)
     for idx, k in enumerate(range(L - 1, -1, -1)):
-        x = torch.cat((x, skips.pop()), dim=1)
-        x = unet_block(P, cfg, f"up_layers.{idx}", x, emb, k in cfg["attn_layers"], True)
-    x = conv_block(P, "out_layers.0", x)
-    x = conv_block(P, "out_layers.1", x, act=False)
+        skip = skips.pop()
+        x = torch.cat((x, skip if Q is None else Q.grad(skip)), dim=1)
+        x = unet_block(P, cfg, f"up_layers.{idx}", x, emb, k in cfg["attn_layers"], True, Q=Q)
+    x = conv_block(P, "out_layers.0", x, Q=Q)
+    x = conv_block(P, "out_layers.1", x, act=False, Q=Q, edge="head")
     if cfg["image_recon"]:
         x = torch.tanh(x)
     return x

@@ -161,6 +161,7 @@ static int g_order_next = -1;
 static int g_order_dev = -1;
 
 extern "C" int sdm_stream_order(sdm_stream_t from, sdm_stream_t to) {
+  sdm_plan_taint("sdm_stream_order (a launch plan replays ONE stream's launches)");
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return sdm_set_error(SDM_ERR_LAUNCH, "stream_order: hipGetDevice failed");
   if (g_order_next < 0 || dev != g_order_dev) {      // (re)build the ring on the current device

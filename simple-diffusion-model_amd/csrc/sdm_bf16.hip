@@ -14,19 +14,10 @@
 #define SDM_FAST_SIGMOID
 #include "sdm_common.h"
 
+#include "sdm_bf16_int.h"
+
 #define BKE 64   // reduction elements per K-step (128 bytes)
 #define ROWF 32  // floats per LDS tile row
-
-struct BfLaunch {
-  sdm_igemm_desc d;
-  int splitk, ntn, kchunks, mfast, out_f32;
-  int vec_epi;   // 4-column vector epilogue allowed (N % 4 == 0, 8-byte aligned output / residual rows, 16-byte bias)
-  int gn_stats;  // accumulate per-(image, channel) sum / sum of squares of the stored outputs into d.gn_sums
-  long long out_rows;   // output rows of ONE batch entry (split-K scratch is [batch][out_rows][N])
-  int pow2, lw, lhw;    // prologue shortcuts, as in sdm_igemm.hip: Wt == 1 << lw, Ht * Wt == 1 << lhw
-  int plain_out;        // output row == tile-grid row
-  int pp;               // 8-wave tiles: ping-pong schedule of the two 4-wave halves (see the kernel)
-};
 
 static inline int ilog2_exact_bf(long v) {
   if (v <= 0 || (v & (v - 1)) != 0) return -1;
@@ -1247,9 +1238,12 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
                    : launch_bf<64, 64, 2, 2, 3, false>(L, ntm, st);
   }
   else if (cfg == 2 && fast && L.vec_epi && L.splitk == 1) {
+    // the phase-interleaved kernel of sdm_igemm8.hip (default); SDM_BF16_8PH=0: the one-barrier-per-K-step tile below (A/B)
+    static const char* ph8_s = getenv("SDM_BF16_8PH");
     // SDM_BF16_KE=32: 32-element K-steps on a four-slot ring (three 32 KB tiles in flight instead of one 64 KB tile)
     static const char* ke_s = getenv("SDM_BF16_KE");
-    if (xs && L.pp) rc = launch_bf<256, 256, 2, 4, 2, true, true, 64, true>(L, ntm, st);
+    if (!(ph8_s && ph8_s[0] == '0')) rc = sdm_launch_igemm8_bf16(L, ntm, st);
+    else if (xs && L.pp) rc = launch_bf<256, 256, 2, 4, 2, true, true, 64, true>(L, ntm, st);
     else if (xs && ke_s && atoi(ke_s) == 32) rc = launch_bf<256, 256, 2, 4, 4, true, true, 32>(L, ntm, st);
     else rc = xs ? launch_bf<256, 256, 2, 4, 2, true, true>(L, ntm, st) : launch_bf<256, 256, 2, 4, 2, true>(L, ntm, st);
   }

@@ -1,0 +1,18 @@
+// Internal to the bf16 contraction translation units (sdm_bf16.hip, sdm_igemm8.hip): the launch record the host planner
+// fills for a kernel.
+#pragma once
+#include "sdm_common.h"
+
+struct BfLaunch {
+  sdm_igemm_desc d;
+  int splitk, ntn, kchunks, mfast, out_f32;
+  int vec_epi;   // 4-column vector epilogue allowed (N % 4 == 0, 8-byte aligned output / residual rows, 16-byte bias)
+  int gn_stats;  // accumulate per-(image, channel) sum / sum of squares of the stored outputs into d.gn_sums
+  long long out_rows;   // output rows of ONE batch entry (split-K scratch is [batch][out_rows][N])
+  int pow2, lw, lhw;    // prologue shortcuts, as in sdm_igemm.hip: Wt == 1 << lw, Ht * Wt == 1 << lhw
+  int plain_out;        // output row == tile-grid row
+  int pp;               // 8-wave tiles: ping-pong schedule of the two 4-wave halves (see the kernel)
+};
+
+// sdm_igemm8.hip: the phase-interleaved 256x256 tile (FAST addressing, vector epilogue, no split-K)
+int sdm_launch_igemm8_bf16(const BfLaunch& L, int ntm, hipStream_t st);

@@ -35,10 +35,15 @@ MOD_TABLE_MAX_BYTES = 1 << 30
 class _StepRunner:
     """Owns the static buffers of one sampling run and replays the captured step."""
 
-    def __init__(self, net, x_t, t_steps, coef, cond_img, labels, noise, use_graph, cfg_scale=None):
+    def __init__(self, net, x_t, t_steps, coef, cond_img, labels, noise, use_graph, cfg_scale=None, seed=0):
         dev = x_t.device
         self.net, self.cond_img, self.labels, self.noise = net, cond_img, labels, noise
         self.cfg_scale = cfg_scale
+        ce = getattr(net, "cond_emb", None)
+        if labels is None and ce is not None and getattr(ce, "cond_layer", None) is not None:
+            # the reference fails here too (custom_layers.py:96-97 runs cond_layer(None)); the per-run modulation tables
+            # would otherwise silently drop the conditional term
+            raise ValueError("this U_Net has a label embedding (cond_dim): labels_tensor is required")
         if cfg_scale is not None:
             if labels is None:
                 raise ValueError("classifier-free guidance needs labels")
@@ -54,8 +59,7 @@ class _StepRunner:
         self.graph = None
         self.body = None
         self.use_graph = use_graph
-        # in-kernel noise of the DDPM update: Philox key drawn from torch's (seedable) default generator once per run
-        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.seed = seed      # Philox key of the DDPM update's in-kernel noise (ddpm_sampling draws it; 0 elsewhere: unused)
         # AdaGN modulation of every step of the run, tabulated once (the embedding depends on t and the labels only)
         self.mod_time = self.mod_cond = self.mods_cur = self.mod_views = None
         lab = self.labels2 if cfg_scale is not None else labels
@@ -106,7 +110,7 @@ class _StepRunner:
     def run(self, body, on_step):
         if self.use_graph:
             x0 = self.x.clone()
-            s = torch.cuda.Stream()
+            s = _warmup_stream(self.x.device)
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):                               # warm-up: sizes workspaces, sets kernel attributes
                 body()
@@ -150,6 +154,19 @@ class _StepRunner:
             for i in range(self.nsteps):
                 body()
                 on_step(i)
+        lib.check_device_error()      # a bounded device-side wait that gave up (cooperative GroupNorm) is an error, not a NaN image
+
+
+_WARMUP_STREAMS = {}
+
+
+def _warmup_stream(device):
+    """ONE side stream per device for the warm-up step in front of a capture (a fresh stream per run would leave one set of
+    per-stream scratch behind per run, ops._StreamKeyed)."""
+    st = _WARMUP_STREAMS.get(device)
+    if st is None:
+        st = _WARMUP_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
 
 
 def _require_cuda(x_t):
@@ -174,7 +191,12 @@ def ddpm_sampling(diffusion_net, noise_degradation, x_t, min_noise=1, max_noise=
         labels_tensor = labels_tensor.to(dev)
     if noise is not None:
         noise = noise.to(dev).float().contiguous()
-    r = _StepRunner(diffusion_net, x_t, steps, coef, cond_img, labels_tensor, noise, _use_graph(use_graph), cfg_scale)
+    # z ~ N(0, 1) of the update (reference :43, torch.randn_like on the device) is drawn IN the update kernel (Philox4x32-10,
+    # Box-Muller); its key comes from the DEVICE generator, so torch.cuda.manual_seed / torch.manual_seed govern the
+    # samples as they do in the reference (the stream itself differs from torch's: INTEGRATION.md).  Only this sampler
+    # draws: the deterministic DDIM / cold samplers leave every generator untouched.
+    seed = int(torch.randint(0, 2 ** 62, (1,), device=dev).item()) if noise is None else 0
+    r = _StepRunner(diffusion_net, x_t, steps, coef, cond_img, labels_tensor, noise, _use_graph(use_graph), cfg_scale, seed=seed)
 
     def body():
         r.begin()

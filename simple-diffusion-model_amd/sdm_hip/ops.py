@@ -172,7 +172,8 @@ class capture_scope:
     rebuilt the y_scale tables, and dereferenced a job table that the allocator had handed to someone else).  So whoever
     captures a graph opens a scope; every cache that hands out a buffer during the capture registers it with keep(); the
     scope's list is stored next to the graph and dies with it.  The caches themselves can then be bounded (LRU) without
-    ever freeing what a live graph still needs."""
+    ever freeing what a live graph still needs.
+
     The scope also OWNS the single-stream state of the capture (_StreamKeyed): the graph's launches use buffers of their
     own, made here, before the capture starts."""
     _stack = []

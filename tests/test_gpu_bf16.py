@@ -311,9 +311,11 @@ def test_groupnorm_statistics_from_the_conv_epilogue(dev, n, c, h, w, expect):
     assert ops._all_zero(ops.GNSUMS)
 
 
-@pytest.mark.parametrize("force", ["2,1", "3,1", "2,1+pingpong"])
+@pytest.mark.parametrize("force", ["2,1", "2,1+legacy", "3,1", "2,1+pingpong"])
 def test_large_tile_configurations_forced(force):
-    """The 256x256 / 8-wave tiles of sdm_igemm_bf16 and sdm_wgrad_bf16 (planned only for launches that fill the chip with
+    """The 256x256 / 8-wave tiles of sdm_igemm_bf16 (the phase-interleaved kernel of sdm_igemm8.hip: "2,1"; the
+    one-barrier-per-K-step tiles it replaced, kept for A/B: "+legacy" = SDM_BF16_8PH=0, "3,1", "+pingpong") and
+    sdm_wgrad_bf16 (planned only for launches that fill the chip with
     them) forced onto every shape that can take them (SDM_BF16_FORCE; read once per process -> subprocess): ragged M / N far below the tile, concat
     sources, residual epilogues, fp32 scores, GroupNorm statistics, data gradients and the golden-pinned U-Net forward."""
     import subprocess
@@ -321,10 +323,13 @@ def test_large_tile_configurations_forced(force):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     pp = force.endswith("+pingpong")       # the opt-in ping-pong schedule of the 8-wave tile (SDM_BF16_PP=1), same cases
+    legacy = pp or force.endswith("+legacy")
     force = force.split("+")[0]
     env = dict(os.environ, SDM_BF16_FORCE=force, SDM_WGRAD_BF16_FORCE="256,2")     # weight gradients: 256x256 tile, 2 slices
     if pp:
         env["SDM_BF16_PP"] = "1"
+    if legacy:
+        env["SDM_BF16_8PH"] = "0"
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_bf16.py"),
                         os.path.join(here, "test_gpu_bf16_train.py"), "-q", "-x", "-k",

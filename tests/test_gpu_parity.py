@@ -1253,3 +1253,122 @@ def test_launch_plan_replays_the_sampling_step(dev, O):
     # guidance: the 2N batch is built with torch.cat -> not planned, still correct (covered by the guidance tests)
     out = S.ddim_sampling(net, sch, xT, 1, 1000, None, torch.eye(3)[[0, 1]].cuda(), 250, "cuda", quiet, use_graph=True, cfg_scale=2.0)
     assert bool(torch.isfinite(out).all())
+
+
+def test_concurrent_forwards_on_two_streams_do_not_share_exchange_state(dev, O):
+    """Two no-grad forwards at 64x64 (the maps the cooperative GroupNorm tail serves) enqueued on two streams of one process:
+    each stream has its own exchange words and its own zero-filled scratch (ops._StreamKeyed), so both equal the
+    single-stream result.  (the state used to be one buffer per device.)"""
+    from models.U_Net import U_Net
+    from sdm_hip import lib, ops
+    cfg = O.full_cfg(dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=64, cond_dim=None, num_layers=2,
+                          attn_layers=[1], num_heads=1, dim_per_head=None, min_channel=128, max_channel=256))
+    P = O.seeded_params(cfg, seed=11, gain=1.5)
+    net = U_Net(**cfg)
+    net.load_state_dict(P, strict=True)
+    net = net.cuda().eval()
+    g = torch.Generator().manual_seed(2)
+    xs = [torch.randn(1, 3, 64, 64, generator=g).cuda() for _ in range(2)]
+    ts = [torch.tensor([400]).cuda(), torch.tensor([17]).cuda()]
+    with torch.no_grad():
+        want = [net(x, t, None).clone() for x, t in zip(xs, ts)]
+        torch.cuda.synchronize()
+        coop_states = len(ops._GN_COOP_STATE.by_stream)
+        assert coop_states >= 1, "the 64x64 tail did not take the cooperative kernel"
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        got = [None, None]
+        for rep in range(6):                     # interleaved enqueues: the two forwards overlap on the device
+            for i, s in enumerate(streams):
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    got[i] = net(xs[i], ts[i], None)
+        torch.cuda.synchronize()
+    for i in range(2):
+        assert rel(got[i], want[i]) < 1e-6, (i, rel(got[i], want[i]))
+    assert len(ops._GN_COOP_STATE.by_stream) >= coop_states + 2        # one state per launching stream
+    for st in ops._GN_COOP_STATE.by_stream.values():
+        assert int(st.to(torch.int32).abs().sum()) == 0
+    assert ops._all_zero(ops.WS)
+    lib.check_device_error()
+
+
+def test_cooperative_groupnorm_wait_is_bounded_and_reported():
+    """The inter-slab wait of sdm_gn_apply_coop gives up after its timeout: with the test hook a slab expects one arrival that
+    never comes (SDM_GN_COOP_TEST_EXTRA=1) and a 2 ms bound -- the launch ENDS, the outputs are NaN, the exchange state is
+    zero again, and the next library call returns SDM_ERR_DEVICE naming the kernel (sdm_device_error_init / _poll).
+    Subprocess: the hook is read from the environment."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    code = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from sdm_hip import lib, ops
+from sdm_hip.ops import Act
+n, h, w, c = 1, 64, 64, 128
+g = torch.Generator().manual_seed(1)
+y = Act(torch.randn(n * h * w, c, generator=g).cuda(), n, h, w)
+gamma, beta = torch.ones(c).cuda(), torch.zeros(c).cuda()
+out = ops.gn_apply_fused(y, gamma, beta, None, 32).t
+torch.cuda.synchronize()
+assert bool(torch.isnan(out).all()), "a slab that gave up must write NaN"
+st = ops._gn_coop_state(y.t.device)
+assert int(st.to(torch.int32).abs().sum()) == 0, "exchange state not zero after a failed exchange"
+try:
+    lib.check_device_error()
+except lib.SdmError as e:
+    assert "sdm_gn_apply_coop" in str(e) and "rc=-4" in str(e), str(e)
+else:
+    raise AssertionError("the failure word was not reported")
+lib.check_device_error()          # reported once, then clear
+print("bounded-ok")
+'''
+    env = dict(os.environ, SDM_GN_COOP_TEST_EXTRA="1", SDM_GN_COOP_TIMEOUT_MS="2")
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "simple-diffusion-model_amd")
+    r = subprocess.run([sys.executable, "-c", code, pkg], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "bounded-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_cooperative_groupnorm_declines_wide_groups(dev):
+    """ADVICE r3: a GroupNorm group wider than one wave's 64 channel quads (groups = 2 at C = 1024) is outside the cooperative
+    kernel's shuffle reduction; it must decline (the per-group kernel runs) and the result must equal the fp64 statistics."""
+    from sdm_hip import ops
+    from sdm_hip.ops import Act
+    n, h, w, c, groups = 1, 32, 32, 1024, 2
+    g = torch.Generator().manual_seed(9)
+    y = torch.randn(n * h * w, c, generator=g).to(dev)
+    gamma, beta = (1 + 0.1 * torch.randn(c, generator=g)).to(dev), (0.1 * torch.randn(c, generator=g)).to(dev)
+    out = ops.gn_apply_fused(Act(y, n, h, w), gamma, beta, None, groups).t
+    yd = y.double().view(n, h * w, groups, c // groups)
+    mu = yd.mean(dim=(1, 3), keepdim=True)
+    var = yd.var(dim=(1, 3), unbiased=False, keepdim=True)
+    want = ((yd - mu) / torch.sqrt(var + 1e-5)).view(n * h * w, c) * gamma.double() + beta.double()
+    assert rel(out, want) < 1e-5, rel(out, want)
+
+
+def test_sampler_requires_labels_for_a_conditional_net(dev, O):
+    """ADVICE r3: a net with a label embedding sampled without labels must fail loudly (the reference runs cond_layer(None),
+    custom_layers.py:96-97) instead of silently dropping the conditional term through the per-run modulation tables; and
+    only the DDPM sampler draws from a generator (the device one), the deterministic samplers leave the RNG state alone."""
+    import degraders as D
+    import diffusion_sampling_algorithms as S
+    cfg, net = narrow_net(O)
+    xT = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(4)).cuda()
+    sch = D.CosineNoiseDegradation(1000)
+    quiet = lambda *a, **k: None
+    with pytest.raises(ValueError):
+        S.ddim_sampling(net, sch, xT, 1, 1000, None, None, 250, "cuda", quiet)
+    with pytest.raises(ValueError):
+        S.ddpm_sampling(net, sch, xT, 1, 4, None, None, "cuda", quiet)
+    lab = torch.tensor([1.0, 0.0, 0.0]).cuda()
+    cpu_state, dev_state = torch.get_rng_state(), torch.cuda.get_rng_state()
+    S.ddim_sampling(net, sch, xT, 1, 1000, None, lab, 250, "cuda", quiet)
+    assert torch.equal(cpu_state, torch.get_rng_state()) and torch.equal(dev_state, torch.cuda.get_rng_state())
+    torch.cuda.manual_seed(5)
+    a = S.ddpm_sampling(net, sch, xT, 1, 6, None, lab, "cuda", quiet)
+    torch.cuda.manual_seed(5)
+    b = S.ddpm_sampling(net, sch, xT, 1, 6, None, lab, "cuda", quiet)
+    c = S.ddpm_sampling(net, sch, xT, 1, 6, None, lab, "cuda", quiet)
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-5) and not torch.allclose(a, c, rtol=1e-2, atol=1e-3)    # (split-K atomics: not bitwise)
+    assert torch.equal(cpu_state, torch.get_rng_state())             # the key comes from the DEVICE generator
