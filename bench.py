@@ -265,6 +265,8 @@ def other_configs(dev, sched, net64):
             rec.update(dtype=dtype, batch=n, images_per_s=n * 1e3 / ms, launches_per_step=launches,
                        what="per-GPU training step (q-sample, forward, MSE, backward, Adam), 4 steps timed")
             out[key + ("" if dtype == "f32" else "_bf16")] = rec
+    # ---- the N=1 point of C4's strong-scaling curve (global batch 256 on one GPU); N>1 points: multi_gpu.c4_strong
+    out["c4_strong_global256"] = c4_strong_scaling(dev, sched, 1)
     return out
 
 
@@ -317,7 +319,39 @@ def multi_gpu_report(dev, world, rank, sched, tr64, x64):
         del tr, net, x0
         torch.cuda.empty_cache()
     rep["c4_config"] = "128x128, 32 images per GPU, DDPM training, global batch %d; fp32 and bf16 storage" % (32 * world)
+    rep["c4_strong"] = c4_strong_scaling(dev, sched, world)
+    rep["dp_backend"], rep["dp_wire"] = tr64.exchange.backend, tr64.exchange.wire
     return rep
+
+
+def c4_strong_scaling(dev, sched, world):
+    """BASELINE configs[3] as SURVEY §8d defines it: GLOBAL batch 256 at 128x128, fixed; every rank trains 256 / world images
+    per step ("256x1, 128x2, 64x4, 32x8").  The N=1 line of that curve is the same function called with world == 1 from
+    other_configs().  Time = max over ranks; images_per_s = 256 / that."""
+    from models.U_Net import U_Net
+    from sdm_hip.trainer import DiffusionTrainer
+    out = {"global_batch": 256, "per_gpu_batch": 256 // world, "scaling": "strong"}
+    for tag, kw in (("bf16", {"train_dtype": torch.bfloat16}), ("f32", {})):
+        torch.manual_seed(0)
+        net = tr = x0 = None
+        try:
+            net = U_Net(**STANDARD).to(dev)
+            tr = DiffusionTrainer(net, sched, lr=2e-5, seed=78, **kw)
+            x0 = torch.randn(256 // world, 3, 128, 128, device=dev)
+            torch.cuda.reset_peak_memory_stats(dev)
+            if world > 1:
+                dist.barrier()
+            ms = time_gpu(lambda: tr.step(x0), 1, 3)
+            if world > 1:
+                tm = torch.tensor([ms], device=dev, dtype=torch.float64)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                ms = float(tm)
+            out[tag] = {"ms_per_step": ms, "images_per_s": 256 * 1e3 / ms, "peak_mem_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+        except torch.OutOfMemoryError:
+            out[tag] = {"ms_per_step": None, "note": "%d images per GPU do not fit" % (256 // world)}
+        del tr, net, x0
+        torch.cuda.empty_cache()
+    return out
 
 
 def launch_ranks(n, argv):
@@ -478,13 +512,16 @@ def main():
         del tr
         configs = other_configs(dev, sched, net.eval())
         for k, v in configs.items():
-            print(f"[bench] {k}: {v['ms_per_step']:.3f} ms/step, flop_frac {v['flop_frac']:.3f}, byte_frac {v['byte_frac']:.3f}",
-                  file=sys.stderr, flush=True)
+            if "ms_per_step" in v:
+                print(f"[bench] {k}: {v['ms_per_step']:.3f} ms/step, flop_frac {v['flop_frac']:.3f}, byte_frac {v['byte_frac']:.3f}",
+                      file=sys.stderr, flush=True)
+            else:
+                print(f"[bench] {k}: {json.dumps(v)}", file=sys.stderr, flush=True)
 
     # HBM bytes per launch of each class from the committed rocprofv3 PMC passes of this same command
     # (profiles/*_hbm_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None when the file is absent
     traffic, traffic_file = {}, None
-    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic = {k: v["total"] for k, v in json.load(f)["per_class_hbm_bytes_per_launch"].items()}

@@ -34,6 +34,7 @@ typedef void* sdm_stream_t; /* hipStream_t */
 #define SDM_ERR_ARG (-1)
 #define SDM_ERR_LAUNCH (-2)
 #define SDM_ERR_UNSUPPORTED (-3)
+#define SDM_ERR_COMM (-5)        /* RCCL (or its absence) reported a failure; sdm_last_error() carries RCCL's own text */
 #define SDM_ERR_DEVICE (-4)      /* a kernel reported a failure (a bounded device-side wait gave up); see sdm_device_error_poll */
 
 #define SDM_ACT_NONE 0
@@ -465,8 +466,15 @@ int sdm_step_begin(const int* cursor, const int64_t* t_table, const float* coef_
 /* ++*cursor (saturating at nsteps) as a launch of its own: steps whose update does not go through the kernels above. */
 int sdm_step_advance(int* cursor, int nsteps, sdm_stream_t s);
 
-/* Fused multi-tensor Adam (torch.optim.Adam defaults, train_diffusion.py:214-217): jobs is a DEVICE array. */
-typedef struct sdm_adam_job { float* p; const float* g; float* m; float* v; int64_t n; } sdm_adam_job;
+/* Fused multi-tensor Adam (torch.optim.Adam defaults, train_diffusion.py:214-217): jobs is a DEVICE array.
+ * w16 / w16t (optional, bf16 training path): the kernel also writes the bf16 copy of the updated parameter (same dense
+ * element order) and / or its transposed copy -- the parameter seen as [n / (R * Cc)][R][Cc], the copy as [..][Cc][ldd]
+ * with ldd >= R (columns [R, ldd) are not touched: the first sdm_cast_bf16_t zero-filled them) -- so the next step's
+ * contractions find their weight copies without the ~470 cast launches per step. */
+typedef struct sdm_adam_job {
+  float* p; const float* g; float* m; float* v; int64_t n;
+  uint16_t* w16; uint16_t* w16t; int R, Cc, ldd, reserved;
+} sdm_adam_job;
 int sdm_adam_multi(const sdm_adam_job* jobs_dev, int njobs, int64_t max_n, float lr, float beta1, float beta2,
                    float eps, float bias_c1, float bias_c2, float grad_scale, const float* hyper_dev, sdm_stream_t s);
 /* hyper_dev (optional, DEVICE, 2 floats {lr, step}): when given, lr and the bias corrections 1-beta^step are read /
@@ -566,6 +574,33 @@ int sdm_head_conv_wgrad_bf16(const uint16_t* x_nhwc, const float* g_nchw, float*
  * channel side of the edge convs in the row format of the matrix-core kernels, whose weight / data gradients then run on
  * sdm_wgrad_bf16 / sdm_igemm_bf16 (U_Net.py:55-60,121-128 backward). */
 int sdm_nchw_to_rows_bf16(const float* x_nchw, uint16_t* out_rows, int images, int C, int H, int W, int Cp, sdm_stream_t s);
+
+/* ---- data-parallel gradient exchange, communicator owned by the library (north_star: "an RCCL all-reduce of
+ * U-Net gradients over xGMI overlapped with the optimizer step").  The reference has no counterpart: it trains on one
+ * device (train_diffusion.py:49).  RCCL is bound at run time (librccl.so.1, the copy the process already holds); without
+ * it every call returns SDM_ERR_COMM.  One communicator per process and GPU; rank 0 makes the 128-byte id
+ * (sdm_dp_unique_id) and the launcher hands it to every rank (torch.distributed broadcast, a file, the environment). */
+typedef struct sdm_dp_comm* sdm_dp_comm_t;
+#define SDM_DP_ID_BYTES 128
+/* > 0: RCCL's version code (it can be loaded); < 0: SDM_ERR_COMM with the reason */
+int sdm_dp_available(void);
+int sdm_dp_unique_id(void* out_id, size_t bytes);
+/* Collective over all `world` ranks, on the calling thread's current HIP device. */
+int sdm_dp_init(const void* id, size_t bytes, int rank, int world, sdm_dp_comm_t* out);
+int sdm_dp_rank(sdm_dp_comm_t c);
+int sdm_dp_world(sdm_dp_comm_t c);
+/* Sum (average != 0: mean) of the fp32 gradient slice buf[0, count) over all ranks, in place, enqueued on `stream`
+ * (any 4-byte aligned start: bucket boundaries fall on arbitrary elements).  wire_bf16 == 0: one ncclAllReduce in fp32.  wire_bf16 != 0: the mesh exchange for the
+ * switchless xGMI topology -- shards rounded to bf16, all-to-all over W - 1 point-to-point transfers, FP32 sum of the W
+ * copies on the owning rank (rank order: deterministic), one rounding of the sum, bf16 all-gather; staging comes from the
+ * communicator (sdm_dp_reserve sizes it ahead of time; otherwise the first bucket of a new maximum size allocates). */
+int sdm_dp_allreduce_bucket(sdm_dp_comm_t c, float* buf, int64_t count, int wire_bf16, int average, sdm_stream_t stream);
+int sdm_dp_reserve(sdm_dp_comm_t c, int64_t max_count);
+/* 0 while the communicator is healthy; SDM_ERR_COMM once RCCL has recorded an asynchronous failure (a lost peer, a
+ * network error): the trainer polls it once per step instead of hanging in the next collective. */
+int sdm_dp_async_error(sdm_dp_comm_t c);
+/* Collective; frees the staging and the communicator.  The handle is dead afterwards. */
+int sdm_dp_finalize(sdm_dp_comm_t c);
 
 #ifdef __cplusplus
 }

@@ -16,3 +16,13 @@ struct BfLaunch {
 
 // sdm_igemm8.hip: the phase-interleaved 256x256 tile (FAST addressing, vector epilogue, no split-K)
 int sdm_launch_igemm8_bf16(const BfLaunch& L, int ntm, hipStream_t st);
+
+// Launch record of the three-taps-per-workgroup weight-gradient kernels (wgrad3_bf16_kernel in sdm_bf16_train.hip, the
+// phase-interleaved wgrad8x3_bf16_kernel in sdm_wgrad8.hip)
+struct Wgrad3Launch {
+  sdm_wgrad_desc d;
+  int splitk, ntn, atomic_out;
+  int dy[3];           // kernel-row offsets handled by blockIdx.y = 0..2
+  int tapw[3][3];      // weight tap index of (dy index, dx = -1, 0, +1)
+};
+int sdm_launch_wgrad8x3_bf16(const Wgrad3Launch& L3, hipStream_t st);

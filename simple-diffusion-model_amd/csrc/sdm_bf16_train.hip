@@ -11,9 +11,10 @@
 //   pointwise              : GroupNorm/AdaGN backward, column-softmax backward, SiLU backward, edge-conv gradients on bf16 rows
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #define SDM_FAST_SIGMOID
-#include "sdm_common.h"
+#include "sdm_bf16_int.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -28,6 +29,23 @@ __device__ __forceinline__ int xcd_contiguous_wg(int bid, int total) {   // see 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_wg() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// The transposing LDS read as inline asm (base address + immediate byte offset).  Through the builtin the compiler sees an
+// LDS load next to LDS-DMA stores it cannot disambiguate and puts s_waitcnt vmcnt(0) in front of the first read of every
+// K-step: every stage in flight is drained and the counted vmcnt waits of these kernels meant nothing (rounds 2-3; found in
+// round 4 from the ISA).  The compiler does not know when an asm read lands: every use sits behind an explicit
+// s_waitcnt lgkmcnt(0) and an opaque touch of the registers.
+template <int OFF>
+__device__ __forceinline__ void tr8_wg(s16x4& v, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void cfor_wg(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    cfor_wg<I + 1, N>(f);
+  }
 }
 
 struct WgradBfLaunch {
@@ -220,7 +238,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(const WgradBfL
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  typedef __attribute__((address_space(3))) s16x4* tr_ptr;
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr)smem_wg;
 #pragma unroll
   for (int pp = 0; pp < PD; ++pp) issue_next();
   for (int it = it0; it < it1; ++it) {
@@ -232,7 +250,6 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(const WgradBfL
     __builtin_amdgcn_s_barrier();
     issue_next();
     const char* Ab = As + buf * TILEB;
-    const char* Bb = Bs + buf * TILEB;
     if (do_bias && tid < BT) {   // column sums of the gradient tile (bias gradient); channel tid
       float a = 0.f;
 #pragma unroll 8
@@ -242,20 +259,31 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(const WgradBfL
       }
       bacc += a;
     }
-#pragma unroll
-    for (int kk = 0; kk < BKP / 16; ++kk) {
-      s16x8 af[TM], bf[TN];
+    const unsigned Aa = lds_base + buf * TILEB, Ba = lds_base + (NBUF + buf) * TILEB;
+    cfor_wg<0, BKP / 16>([&](auto kc) {
+      constexpr int kk = decltype(kc)::value;
+      s16x4 al[TM], ah[TM], bl[TN], bh[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Ab + aoff[i] + (kk * 16) * ROWB));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Ab + aoff[i] + (kk * 16 + 4) * ROWB));
-        af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        tr8_wg<(kk * 16) * ROWB>(al[i], Aa + aoff[i]);
+        tr8_wg<(kk * 16 + 4) * ROWB>(ah[i], Aa + aoff[i]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Bb + boff[j] + (kk * 16) * ROWB));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Bb + boff[j] + (kk * 16 + 4) * ROWB));
-        bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        tr8_wg<(kk * 16) * ROWB>(bl[j], Ba + boff[j]);
+        tr8_wg<(kk * 16 + 4) * ROWB>(bh[j], Ba + boff[j]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      s16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        asm volatile("" : "+v"(al[i]), "+v"(ah[i]));
+        af[i] = __builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        asm volatile("" : "+v"(bl[j]), "+v"(bh[j]));
+        bf[j] = __builtin_shufflevector(bl[j], bh[j], 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -263,7 +291,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(const WgradBfL
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
                                                               __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
-    }
+    });
   }
   if (do_bias && tid < BT && m0 + tid < d.M) atomicAdd(&d.dbias[m0 + tid], bacc);
 
@@ -319,12 +347,7 @@ static int launch_wgrad_bf16(const WgradBfLaunch& L, int ntm, hipStream_t st) {
 // from the same LDS image (fragment rows shifted by 1 + dx, swizzle taken from the shifted row): a third of the bytes per
 // flop, 48 instead of 16 MFMAs per wave and barrier, 1.33 instead of 2 transposing reads per MFMA.
 // --------------------------------------------------------------------------------------------
-struct Wgrad3Launch {
-  sdm_wgrad_desc d;
-  int splitk, ntn, atomic_out;
-  int dy[3];           // kernel-row offsets handled by blockIdx.y = 0..2
-  int tapw[3][3];      // weight tap index of (dy index, dx = -1, 0, +1)
-};
+// (Wgrad3Launch: sdm_bf16_int.h)
 
 #define W3_XROWS 68     // 66 activation pixels per K-step, padded to whole 4-row DMA instructions
 
@@ -447,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_bf16_kernel(const Wgrad3Launch 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
 
-  typedef __attribute__((address_space(3))) s16x4* tr_ptr;
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr)smem_w3;
   issue_next();
   for (int it = it0; it < it1; ++it) {
     const int buf = (it - it0) & 1;
@@ -455,30 +478,43 @@ __global__ __launch_bounds__(256, 2) void wgrad3_bf16_kernel(const Wgrad3Launch 
     __builtin_amdgcn_s_barrier();
     issue_next();
     const char* Ab = Gs + buf * GT;
-    const char* Bb = Xs + buf * XT;
     if (do_bias && tid < BT) {
       float a = 0.f;
 #pragma unroll 8
       for (int k = 0; k < BKP; ++k) a += bf2f(*(const bf16_t*)(Ab + k * ROWB + (((tid >> 3) ^ ((k & 3) << 2)) << 4) + ((tid & 7) << 1)));
       bacc += a;
     }
-#pragma unroll
-    for (int kk = 0; kk < BKP / 16; ++kk) {
-      s16x8 af[TM];
+    const unsigned Aa = lds_base + buf * GT, Ba = lds_base + NBUF * GT + buf * XT;
+    cfor_wg<0, BKP / 16>([&](auto kc) {
+      constexpr int kk = decltype(kc)::value;
+      s16x4 al[TM], ah[TM];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Ab + aoff[i] + (kk * 16) * ROWB));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Ab + aoff[i] + (kk * 16 + 4) * ROWB));
-        af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        tr8_wg<(kk * 16) * ROWB>(al[i], Aa + aoff[i]);
+        tr8_wg<(kk * 16 + 4) * ROWB>(ah[i], Aa + aoff[i]);
       }
+      s16x8 af[TM];
 #pragma unroll
       for (int sft = 0; sft < 3; ++sft) {
+        s16x4 bl[TN], bh[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          tr8_wg<(kk * 16) * ROWB>(bl[j], Ba + boff[sft][j]);
+          tr8_wg<(kk * 16 + 4) * ROWB>(bh[j], Ba + boff[sft][j]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (sft == 0) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            asm volatile("" : "+v"(al[i]), "+v"(ah[i]));
+            af[i] = __builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+        }
         s16x8 bf[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Bb + boff[sft][j] + (kk * 16) * ROWB));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(Bb + boff[sft][j] + (kk * 16 + 4) * ROWB));
-          bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          asm volatile("" : "+v"(bl[j]), "+v"(bh[j]));
+          bf[j] = __builtin_shufflevector(bl[j], bh[j], 0, 1, 2, 3, 4, 5, 6, 7);
         }
         if (WSH < 6 && sft != 1) {          // narrow maps: gradient pixels at x == 0 (dx = -1) / x == W - 1 (dx = +1) have no neighbour
           const bool grp = WSH == 4 || (sft == 0 ? (kk & 1) == 0 : (kk & 1) == 1);
@@ -494,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_bf16_kernel(const Wgrad3Launch 
             acc[sft][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
                                                                      __builtin_bit_cast(bf16x8, bf[j]), acc[sft][i][j], 0, 0, 0);
       }
-    }
+    });
   }
   if (do_bias && tid < BT && m0 + tid < d.M) atomicAdd(&d.dbias[m0 + tid], bacc);
 
@@ -592,7 +628,7 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
     }
   }
   // three taps per workgroup (wgrad3_bf16_kernel): plain 3x3 stride-1 geometry on maps at least 64 pixels wide
-  bool use3 = false;
+  bool use3 = false, use8 = false;
   Wgrad3Launch L3;
   {
     static const char* w3 = getenv("SDM_WGRAD3");                // "0": off; "1": on wherever eligible (tests); default: cost model
@@ -600,7 +636,7 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
     bool ok = !(w3 && w3[0] == '0') && d->ntaps == 9 && d->batch == 1 && d->g_stride == 1 && d->x_stride == 1 &&
               (d->Wk % BKP == 0 || ((d->Wk == 32 || d->Wk == 16) && ((long)d->Hk * d->Wk) % BKP == 0)) &&
               d->g.H == d->Hk && d->g.W == d->Wk && d->x.H == d->Hk && d->x.W == d->Wk &&
-              (fbt == 0 || fbt == 3);
+              (fbt == 0 || fbt == 3 || fbt == 8);
     int seen[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int t = 0; ok && t < 9; ++t) {
       const int ty = d->x_dy[t], tx = d->x_dx[t];
@@ -628,7 +664,24 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
       // the 3- / 6-channel edge convs (one side of the tile almost empty) on full-resolution maps: measured 223 -> 162 us at
       // 524288 pixels, which the per-tap model (calibrated on full tiles) does not see
       const bool edge = (d->M < 64 || d->N < 64) && T >= 1024;
-      if ((w3 && w3[0] == '1') || fbt == 3 || best3 < best_other || edge) {
+      // the phase-interleaved form of the same tile (sdm_wgrad8.hip): one 8-wave workgroup per CU
+      static const char* w8 = getenv("SDM_WGRAD8");               // "0": off; "1": wherever eligible (tests); default: cost model
+      static const char* t8s = getenv("SDM_WGRAD8_T");            // calibration override of its step time [us]
+      double best8 = 1e30;
+      int sk8 = 1;
+      if ((!(w8 && w8[0] == '0') && !(w3 && w3[0] == '1' && !w8) && fbt == 0) || fbt == 8) {
+        const double t8 = t8s ? atof(t8s) * 1e-6 : 1.55e-6;       // one K-step of a full wave of 256 workgroups (3 taps each)
+        for (int c = 1; c <= 256 && c <= (T >= 4 ? T / 4 : 1); ++c) {
+          const double t = ceil((double)blocks3 * c / 256.0) * (ceil((double)T / c) * t8 + 3.0e-6) +
+                           (c > 1 || d->accumulate == 1 ? out_bytes * c / 1.3e12 : out_bytes / 5e12);
+          if (t < best8 * 0.97) { best8 = t; sk8 = c; }
+        }
+      }
+      if ((w8 && w8[0] == '1' && best8 < 1e30) || fbt == 8 || (best8 < best3 && (best8 < best_other || edge))) {
+        use3 = use8 = true;
+        sk = (fbt == 8 && fsk >= 1 && fsk <= T) ? fsk : sk8;
+        for (int i = 0; i < 3; ++i) L3.dy[i] = i - 1;
+      } else if ((w3 && w3[0] == '1') || fbt == 3 || best3 < best_other || edge) {
         use3 = true;
         sk = (fbt == 3 && fsk >= 1 && fsk <= T) ? fsk : sk3;
         for (int i = 0; i < 3; ++i) L3.dy[i] = i - 1;
@@ -654,6 +707,7 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
     L3.splitk = sk;
     L3.atomic_out = L.atomic_out;
     L3.ntn = cdiv(d->N, 128);
+    if (use8) return sdm_launch_wgrad8x3_bf16(L3, st);
     constexpr size_t lds3 = (size_t)2 * (BKP * 256 + W3_XROWS * 256);
     static bool attr3 = false;
     if (!attr3) {

@@ -1264,9 +1264,22 @@ extern "C" int sdm_step_advance(int* cursor, int nsteps, sdm_stream_t s) {
 // --------------------------------------------------------------------------------------------
 // fused multi-tensor Adam (no weight decay, bias-corrected; torch.optim.Adam semantics)
 // --------------------------------------------------------------------------------------------
+__device__ __forceinline__ float adam_element(const sdm_adam_job& j, long long i, float gscale, float b1, float b2, float step,
+                                              float rs, float eps) {
+  const float g = j.g[i] * gscale;
+  const float m = j.m[i] + (1.f - b1) * (g - j.m[i]);  // lerp, as torch does
+  const float v = b2 * j.v[i] + (1.f - b2) * g * g;
+  j.m[i] = m;
+  j.v[i] = v;
+  const float p = j.p[i] - step * (m / (sqrtf(v) * rs + eps));
+  j.p[i] = p;
+  return p;
+}
+
 __global__ __launch_bounds__(256) void adam_multi_kernel(const sdm_adam_job* __restrict__ jobs, float lr, float b1,
                                                          float b2, float eps, float bc1, float bc2, float gscale,
                                                          const float* __restrict__ hyper) {
+  __shared__ bf16_t tile[64][72];      // [c][r] of a 64 x 64 block of the updated weight (transposed copy); 144-byte rows
   const sdm_adam_job j = jobs[blockIdx.y];
   if (hyper) {
     lr = hyper[0];
@@ -1276,13 +1289,48 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const sdm_adam_job* __r
   }
   const float step = lr / bc1;
   const float rs = 1.0f / sqrtf(bc2);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < j.n; i += (long long)gridDim.x * 256) {
-    const float g = j.g[i] * gscale;
-    const float m = j.m[i] + (1.f - b1) * (g - j.m[i]);  // lerp, as torch does
-    const float v = b2 * j.v[i] + (1.f - b2) * g * g;
-    j.m[i] = m;
-    j.v[i] = v;
-    j.p[i] -= step * (m / (sqrtf(v) * rs + eps));
+  if (!j.w16t) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < j.n; i += (long long)gridDim.x * 256) {
+      const float p = adam_element(j, i, gscale, b1, b2, step, rs, eps);
+      if (j.w16) j.w16[i] = f2bf(p);
+    }
+    return;
+  }
+  // The parameter is [T][R][Cc] (tap-major conv weight / Linear with T = 1) and the bf16 training path reads a
+  // transposed copy [T][Cc][ldd] of it: walk it in 64 x 64 blocks, the update itself coalesced along Cc, the block's
+  // new values through LDS so that the transposed copy is written in 128-byte runs along R.
+  const int R = j.R, Cc = j.Cc, ldd = j.ldd;
+  const int nr = (R + 63) >> 6, nc = (Cc + 63) >> 6;
+  const long long T = j.n / ((long long)R * Cc);
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (long long b = blockIdx.x; b < T * nr * nc; b += gridDim.x) {
+    const long long t = b / (nr * nc);
+    const int rem = (int)(b - t * nr * nc), r0 = (rem / nc) << 6, c0 = (rem % nc) << 6;
+    const long long base = t * R * Cc;
+    const int c = c0 + tx;
+    for (int i = ty; i < 64; i += 4) {
+      const int r = r0 + i;
+      bf16_t h = 0;
+      if (r < R && c < Cc) {
+        const long long e = base + (long long)r * Cc + c;
+        h = f2bf(adam_element(j, e, gscale, b1, b2, step, rs, eps));
+        if (j.w16) j.w16[e] = h;
+      }
+      tile[tx][i] = h;
+    }
+    __syncthreads();
+    bf16_t* o = j.w16t + t * Cc * ldd;
+    if ((ldd & 7) == 0) {
+      for (int e = threadIdx.x; e < 64 * 8; e += 256) {   // 8 consecutive r per lane: one 16-byte store
+        const int ci = e >> 3, r8 = (e & 7) * 8;
+        if (c0 + ci < Cc && r0 + r8 < R)                   // columns [R, ldd) of the copy stay zero (written once by the cast)
+          *(u16x8*)(o + (long long)(c0 + ci) * ldd + r0 + r8) = *(const u16x8*)&tile[ci][r8];
+      }
+    } else {
+      for (int i = ty; i < 64; i += 4)
+        if (c0 + i < Cc && r0 + tx < R) o[(long long)(c0 + i) * ldd + r0 + tx] = tile[i][tx];
+    }
+    __syncthreads();
   }
 }
 extern "C" int sdm_adam_multi(const sdm_adam_job* jobs_dev, int njobs, int64_t max_n, float lr, float beta1, float beta2,

@@ -67,6 +67,12 @@ def bf16_weight(mod, key, src_fn, transposed=False, pad_to=1):
     tag = (w.data_ptr(), w._version, ops.WEIGHT_EPOCH[0])
     cache = mod.__dict__.setdefault("_bf16_cache", {})
     hit = cache.get(key)
+    if hit is not None and len(hit) == 3:
+        # a copy the fused optimizer writes itself, next to the fp32 master (FusedAdam.adopt_bf16_copies): in step with the
+        # weight for as long as that optimizer is the only raw writer and torch has not touched the parameter
+        token, switches = hit[2]
+        if hit[0][:2] == tag[:2] and token is ops._LAST_WRITER[0] and switches == ops.WRITER_SWITCHES[0]:
+            return hit[1]
     if hit is None or hit[0] != tag:
         keep = hit[1] if (hit is not None and hit[0][0] == tag[0]) else None
         if transposed:

@@ -64,7 +64,8 @@ class LinearJob(C.Structure):
 
 
 class AdamJob(C.Structure):
-    _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("n", C.c_int64)]
+    _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("n", C.c_int64),
+                ("w16", fp), ("w16t", fp), ("R", C.c_int), ("Cc", C.c_int), ("ldd", C.c_int), ("reserved", C.c_int)]
 
 
 class SdmError(RuntimeError):
@@ -172,6 +173,16 @@ _PROTOS = {
     "sdm_head_conv_dgrad_bf16": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "sdm_head_conv_wgrad_bf16": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "sdm_nchw_to_rows_bf16": (_i, [fp, fp, _i, _i, _i, _i, _i, fp]),
+    # data-parallel exchange (communicator owned by the library)
+    "sdm_dp_available": (_i, []),
+    "sdm_dp_unique_id": (_i, [C.c_char_p, _sz]),
+    "sdm_dp_init": (_i, [C.c_char_p, _sz, _i, _i, C.POINTER(fp)]),
+    "sdm_dp_rank": (_i, [fp]),
+    "sdm_dp_world": (_i, [fp]),
+    "sdm_dp_allreduce_bucket": (_i, [fp, fp, _i64, _i, _i, fp]),
+    "sdm_dp_reserve": (_i, [fp, _i64]),
+    "sdm_dp_async_error": (_i, [fp]),
+    "sdm_dp_finalize": (_i, [fp]),
 }
 EXPORTS = tuple(_PROTOS)
 

@@ -182,15 +182,23 @@ class capture_scope:
     def current():
         return capture_scope._stack[-1] if capture_scope._stack else None
 
+    _serial = [0]
+
     def __enter__(self):
         self.kept = []
         self.local = {}
+        capture_scope._serial[0] += 1
+        self.serial = capture_scope._serial[0]
         if torch.cuda.is_available():
             dev = torch.cuda.current_device()
             for owner in _StreamKeyed._all:
                 t = owner._prealloc(dev)
                 if t is not None:
                     self.local[(id(owner), dev)] = t
+                    self.kept.append(t)
+            for bank in list(LinearBank._all or ()):
+                t = bank.prealloc_for_capture(self)
+                if t is not None:
                     self.kept.append(t)
         capture_scope._stack.append(self)
         return self.kept
@@ -275,6 +283,18 @@ _WG_C3_COLS = tuple([t[i] for t in _WG_C3] for i in range(5))
 
 BF16 = torch.bfloat16
 WEIGHT_EPOCH = [0]      # bumped whenever weights are rewritten behind torch's back (fused Adam): bf16 copies go stale
+_LAST_WRITER = [None]   # token of the optimizer that bumped it last
+WRITER_SWITCHES = [0]   # how often the identity of that writer changed
+
+
+def weights_written(token):
+    """An optimizer (identified by ``token``) has rewritten weights through raw pointers.  bf16 weight copies tagged with an
+    older epoch are stale -- except copies that this very optimizer keeps up to date itself (FusedAdam.adopt_bf16_copies:
+    sdm_adam_multi writes them together with the fp32 master), which stay valid for as long as no OTHER writer steps in."""
+    WEIGHT_EPOCH[0] += 1
+    if _LAST_WRITER[0] is not token:
+        _LAST_WRITER[0] = token
+        WRITER_SWITCHES[0] += 1
 
 
 def _launch_igemm(d, device, bf16=False, out_f32=False):
@@ -1184,10 +1204,46 @@ class LinearBank:
     tables; rebuilt when a parameter pointer or the embedding batch changes."""
 
     MAX_SETS = 8                   # table sets kept (LRU); a live graph pins the set it captured through capture_scope
+    _all = None                    # weak set of the live banks (capture_scope sizes a set of its own for each)
 
     def __init__(self):
+        import weakref
+        if LinearBank._all is None:
+            LinearBank._all = weakref.WeakSet()
+        LinearBank._all.add(self)
         self.key = None
         self.built = {}            # key -> table set, in least-recently-used order
+
+    _FIELDS = ("sizes", "out", "dout", "views", "dviews", "jobs", "bjobs", "chunk_job", "chunk_o0", "maxO")
+
+    @staticmethod
+    def _user():
+        """Who the output buffers of a table set belong to: the launching stream, or the capture in progress -- like every
+        other single-user buffer of the library (_StreamKeyed).  Two forwards of one net on two streams write their
+        modulation rows into different buffers; a captured graph has a set of its own (made by capture_scope)."""
+        scope = capture_scope.current()
+        return ("capture", scope.serial) if scope is not None else ("stream", _stream())
+
+    def _store(self, key, linears):
+        self.built[key] = {k: getattr(self, k) for k in self._FIELDS}
+        self.built[key]["linears"] = list(linears)
+        while len(self.built) > self.MAX_SETS:            # evict the least recently used set; a graph that
+            self.built.pop(next(iter(self.built)))        # captured it keeps it alive until the graph is destroyed
+
+    def prealloc_for_capture(self, scope):
+        """A table set for the capture that is about to start: same batch and projections as the most recent forward (the
+        capture's warm-up run), buffers and job tables of its own."""
+        if self.key is None or self.key not in self.built:
+            return None
+        cur = self.built[self.key]
+        linears = cur["linears"]
+        saved = {k: getattr(self, k) for k in self._FIELDS}
+        self._build(linears, self.key[0], self.key[1])
+        key = self.key[:4] + (("capture", scope.serial),)
+        self._store(key, linears)
+        for k, v in saved.items():
+            setattr(self, k, v)
+        return self.built[key]
 
     def _build(self, linears, M, dev):
         import ctypes
@@ -1219,20 +1275,18 @@ class LinearBank:
 
     def forward(self, linears, emb, private=False):
         M, K = emb.shape
-        key = (M, emb.device, tuple(l.weight.data_ptr() for l in linears), tuple(l.bias.data_ptr() for l in linears))
+        key = (M, emb.device, tuple(l.weight.data_ptr() for l in linears), tuple(l.bias.data_ptr() for l in linears),
+               self._user())
         if key != self.key:
             if key not in self.built:
                 if torch.cuda.is_current_stream_capturing():
                     raise lib.SdmError("y_scale job tables must be built by a warm-up call before graph capture")
                 self._build(linears, M, emb.device)
-                self.built[key] = {k: getattr(self, k) for k in ("sizes", "out", "dout", "views", "dviews", "jobs", "bjobs",
-                                                                 "chunk_job", "chunk_o0", "maxO")}
-                while len(self.built) > self.MAX_SETS:            # evict the least recently used set; a graph that
-                    self.built.pop(next(iter(self.built)))        # captured it keeps it alive until the graph is destroyed
+                self._store(key, linears)
             else:
                 self.built[key] = self.built.pop(key)             # most recently used last
-                for k, v in self.built[key].items():
-                    setattr(self, k, v)
+                for k in self._FIELDS:
+                    setattr(self, k, self.built[key][k])
             self.key = key
         keep(self.built[key])
         if M >= 64 and BANK_MFMA[0] and emb.is_contiguous():

@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import lib, ops
-from .dp import BucketedAllReduce
+from .dp import BucketedAllReduce, make_exchange
 
 
 class FusedAdam:
@@ -38,17 +38,66 @@ class FusedAdam:
             assert p.stride() == g.stride() == m.stride(), "Adam state must share the parameter layout"
             jobs[j].p, jobs[j].g, jobs[j].m, jobs[j].v, jobs[j].n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
             self.max_n = max(self.max_n, p.numel())
-        raw = bytes(jobs)
-        self.jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.jobs_host = jobs
+        self.jobs_dev = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
         self.njobs = len(params_grads)
         self.job_bytes = C.sizeof(lib.AdamJob)
+        self.token = object()                         # this optimizer's identity for ops.weights_written
+        self.adopted = 0
+
+    def adopt_bf16_copies(self):
+        """bf16 training path: the contractions read bf16 copies of the weights (and transposed copies for the data
+        gradients), cached per module and refreshed by a cast launch whenever the fp32 master changed -- ~470 launches and
+        ~1.1 ms of a ~25 ms step.  After the first step those copies exist; from here on sdm_adam_multi writes them together
+        with the master (their addresses go into the job table), and custom_layers.bf16_weight stops re-casting them.
+        Call on the stream the next forward runs on, after the optimizer stream has been joined.  Returns the number of
+        copies adopted."""
+        from models.custom_layers import bf16_weight
+        index = {id(p): j for j, (p, _) in enumerate(self.items)}
+        n = 0
+        for mod in self.net.modules():
+            cache = mod.__dict__.get("_bf16_cache")
+            w = getattr(mod, "_parameters", {}).get("weight")
+            if not cache or w is None or id(w) not in index:
+                continue
+            job = self.jobs_host[index[id(w)]]
+            for key in list(cache):
+                transposed = key in ("taps_t", "wt")
+                if key not in ("taps", "w", "taps_t", "wt"):
+                    continue
+                # bring the copy in step with the master now (it was cast before the last optimizer step)
+                cache[key] = (("stale",), cache[key][1])
+                src = (lambda m=mod: m.taps()) if key.startswith("taps") else \
+                      ((lambda m=mod: m.weight.detach()[None]) if transposed else (lambda m=mod: m.weight))
+                buf = bf16_weight(mod, key, src, transposed=transposed, pad_to=8 if key == "taps_t" else 1)
+                if transposed:
+                    T, Cc, ldd = buf.shape
+                    R = w.numel() // (T * Cc)
+                    job.w16t, job.R, job.Cc, job.ldd = buf.data_ptr(), R, Cc, ldd
+                else:
+                    assert buf.numel() == w.numel()
+                    job.w16 = buf.data_ptr()
+                n += 1
+        if n:
+            self.jobs_dev.copy_(torch.frombuffer(bytearray(bytes(self.jobs_host)), dtype=torch.uint8))
+            ops.weights_written(self.token)           # this optimizer is the writer the copies follow from here on
+            for mod in self.net.modules():
+                cache = mod.__dict__.get("_bf16_cache")
+                w = getattr(mod, "_parameters", {}).get("weight")
+                if not cache or w is None or id(w) not in index:
+                    continue
+                for key in list(cache):
+                    if key in ("taps", "w", "taps_t", "wt"):
+                        cache[key] = ((w.data_ptr(), w._version, None), cache[key][1], (self.token, ops.WRITER_SWITCHES[0]))
+        self.adopted = n
+        return n
 
     def step(self, first=0, count=None, grad_scale=1.0, advance=True, hyper=None):
         """Update jobs [first, first+count).  ``advance`` bumps the step counter (once per optimiser step).
         ``hyper`` (device [lr, step]) makes lr / bias corrections device-resident (graph replay)."""
         if advance:
             self.step_count += 1
-        ops.WEIGHT_EPOCH[0] += 1                      # weights change behind torch's version counters
+        ops.weights_written(self.token)               # weights change behind torch's version counters
         count = self.njobs - first if count is None else count
         lr = self.param_groups[0]["lr"]
         b1, b2 = self.betas
@@ -87,14 +136,17 @@ class FusedAdam:
 
 class DiffusionTrainer:
     def __init__(self, net, schedule, lr=2e-5, betas=(0.5, 0.999), min_noise_step=1, max_actual_noise_step=1000,
-                 bucket_mb=64, process_group=None, seed=None, use_graph=None, sr=None, train_dtype=None, objective="eps"):
+                 bucket_mb=64, process_group=None, seed=None, use_graph=None, sr=None, train_dtype=None, objective="eps",
+                 dp_backend=None, dp_wire=None):
         """``sr=(lr_dim, sr_dim, cond_t)`` switches to the super-resolution objective of train_SR_diffusion.py:318-374:
         the net sees cat(q(x0, t), q(lowres(x0), cond_t)) and regresses x0 - lowres(x0).
         ``train_dtype=torch.bfloat16`` runs forward/backward in bf16 storage (U_Net.set_training_dtype); weights,
         gradients and Adam stay fp32.
         ``objective``: "eps" regresses the noise (train_diffusion.py:343-352, train_doodle_diffusion.py:300-312); "x0"
         regresses the clean image (cold diffusion, train_noise_cold_diffusion.py:335-342).  An image condition (doodle:
-        ``cat((x_t, lbl_data), 1)``, train_doodle_diffusion.py:304) is passed per step as ``cond_img``."""
+        ``cat((x_t, lbl_data), 1)``, train_doodle_diffusion.py:304) is passed per step as ``cond_img``.
+        ``dp_backend`` ("torch" | "sdm") / ``dp_wire`` ("f32" | "bf16"): who runs the gradient exchange and in which wire
+        format (sdm_hip/dp.py; defaults from SDM_DP_BACKEND / SDM_DP_WIRE, else torch.distributed in fp32)."""
         if objective not in ("eps", "x0"):
             raise ValueError("objective must be 'eps' or 'x0'")
         self.objective = objective
@@ -102,6 +154,10 @@ class DiffusionTrainer:
         if train_dtype is not None:
             net.set_training_dtype(train_dtype)
         self.net, self.schedule = net, schedule
+        # bf16 training: the fused Adam also writes the bf16 (and transposed bf16) weight copies (SDM_ADAM_BF16_COPIES=0: the
+        # copies are re-cast from the fp32 masters every step, as before -- A/B)
+        import os as _os
+        self.adopt_bf16 = train_dtype is not None and _os.environ.get("SDM_ADAM_BF16_COPIES", "1") != "0"
         self.min_t, self.max_t = min_noise_step, max_actual_noise_step
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -115,8 +171,9 @@ class DiffusionTrainer:
             self.items += [(p, self.grads[p]) for p in ps]
             self.block_range[name] = (ranges[name][0], ranges[name][1], j0, len(self.items))
         self.order = [n for n, _ in order]
+        self.exchange = make_exchange(process_group, dp_backend, dp_wire, dev)
         self.reducer = BucketedAllReduce(self.flat, [(n, ranges[n][0], ranges[n][1]) for n in self.order], bucket_mb,
-                                         process_group)
+                                         process_group, exchange=self.exchange)
         # optimizer jobs covered by each bucket
         self.bucket_jobs = []
         for (s, e, first, last) in self.reducer.buckets:
@@ -203,6 +260,8 @@ class DiffusionTrainer:
             self.net._block_done_hook = None
         self.reducer.pending = []
         torch.cuda.current_stream(self.dev).wait_stream(self.opt_stream)   # next forward sees the updated weights
+        if self.adopt_bf16 and not self.opt.adopted and not torch.cuda.is_current_stream_capturing():
+            self.opt.adopt_bf16_copies()               # once, after the first step: Adam keeps the bf16 weight copies itself
         return loss
 
     def step(self, x0, labels=None, eps=None, t=None, cond_img=None):
@@ -255,5 +314,5 @@ class DiffusionTrainer:
             self.hyper[0:1].fill_(lr)
             self._lr_dev = lr
         self.graph.replay()
-        ops.WEIGHT_EPOCH[0] += 1          # the replayed Adam rewrote the weights: bf16 copies of no-grad forwards are stale
+        ops.weights_written(self.opt.token)   # the replayed Adam rewrote the weights: bf16 copies of no-grad forwards are stale
         return self.g_loss

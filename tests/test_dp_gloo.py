@@ -68,3 +68,89 @@ def test_bucketed_allreduce_world2_gloo():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     assert len({n for _, _, n in res}) == 1
+
+
+# ---- exchange selection (SDM_DP_BACKEND / SDM_DP_WIRE, DiffusionTrainer(dp_backend=, dp_wire=)) and the bf16 wire --------
+def _mesh_expect(parts, world):
+    """The arithmetic of the bf16-wire exchange written out directly (sdm_hip/dp.py docstring, csrc/sdm_dp.hip): shard s is
+    summed on rank s in fp32 over the ranks in rank order, rank s's own values unrounded, the others rounded to bf16; the sum
+    is rounded to bf16 once."""
+    from sdm_hip.dp import shard_elems
+    n = parts[0].numel()
+    sh = shard_elems(n, world)
+    pad = [torch.cat([p, torch.zeros(world * sh - n)]) for p in parts]
+    out = torch.zeros(world * sh)
+    for s in range(world):
+        acc = torch.zeros(sh)
+        for w in range(world):
+            v = pad[w][s * sh:(s + 1) * sh]
+            acc += v if w == s else v.to(torch.bfloat16).float()
+        out[s * sh:(s + 1) * sh] = acc.to(torch.bfloat16).float()
+    return out[:n]
+
+
+def _worker_bf16(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SDM_DP_WIRE="bf16")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sdm_hip.dp import make_exchange
+        n = 160000
+        parts = [torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) * 10 ** (r - 1) for r in range(world)]
+        flat = parts[rank].clone()
+        ex = make_exchange()                                     # environment: torch backend, bf16 wire
+        red = BucketedAllReduce(flat, BLOCKS, bucket_mb=0.125, exchange=ex)
+        red.begin_step()
+        for name, s, e in BLOCKS:
+            red.block_done(name)
+        spans = [(s, e) for _, s, e in red.drain()]
+        want = torch.cat([_mesh_expect([p[s:e] for p in parts], world) for s, e in spans])
+        exact = torch.stack(parts).double().sum(0)
+        err = float((flat.double() - exact).norm() / exact.norm())
+        q.put((rank, ex.backend, ex.wire, bool(torch.equal(flat, want)), err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_wire_exchange_world2_gloo():
+    """The mesh exchange's arithmetic through torch.distributed (gloo): every rank ends with the SAME values, equal to the
+    direct formula bit for bit; against the exact sum the error is two bf16 roundings (<= 2^-8 relative per element)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bf16, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, backend, wire, same, err in res:
+        assert (backend, wire) == ("torch", "bf16")
+        assert same, res
+        assert err < 2.0 ** -8, res
+
+
+def test_exchange_selection_and_library_communicator_fails_loudly_without_a_gpu(monkeypatch):
+    from sdm_hip import dp, lib
+    assert dp.shard_elems(160000, 2) == 80000 and dp.shard_elems(10, 4) == 8 and dp.shard_elems(17, 2) == 16
+    ex = dp.make_exchange()
+    assert (ex.backend, ex.wire, ex.world) == ("torch", "f32", 1)
+    monkeypatch.setenv("SDM_DP_WIRE", "bf16")
+    assert dp.make_exchange().wire == "bf16"
+    with pytest.raises(ValueError):
+        dp.make_exchange(backend="mpi")
+    with pytest.raises(ValueError):
+        dp.make_exchange(wire="fp8")
+    # one rank, bf16 wire: the exchange is the double rounding alone
+    x = torch.randn(1003)
+    y = x.clone()
+    dp.TorchExchange(None, "bf16").all_reduce(y).wait()
+    assert torch.equal(y, x.to(torch.bfloat16).float())
+    if torch.cuda.is_available():
+        pytest.skip("the rest needs a machine WITHOUT a GPU")
+    # the library-owned communicator: RCCL loads (version code), but there is no device to make a communicator on -> SdmError
+    # through the library's error convention (RCCL's own text or the missing device); nothing falls back to torch.distributed
+    assert lib.raw("sdm_dp_available")() > 20000
+    monkeypatch.setenv("SDM_DP_BACKEND", "sdm")
+    with pytest.raises(lib.SdmError, match="sdm_dp_(unique_id|init) failed"):
+        dp.make_exchange()
+    assert lib.raw("sdm_dp_world")(None) == -1 and "communicator" in lib.last_error()

@@ -317,16 +317,18 @@ def test_colsum_bf16(dev, rows, C, ld):
     assert torch.allclose(out, ref, rtol=1e-4, atol=1e-3 * max(1.0, rows ** 0.5)), float((out - ref).abs().max())
 
 
-def test_three_tap_weight_gradient_kernel_forced():
-    """wgrad3_bf16_kernel (one kernel row = three column taps per workgroup; planned for 3x3 stride-1 convs on maps >= 64
-    pixels wide once the launch is large) forced onto every eligible case of this file (SDM_WGRAD3=1; read once per process
-    -> subprocess): the 64- / 128-wide conv cases above incl. ragged channels, concat rows, accumulation, the fused bias
-    gradient, and the whole-network gradient goldens."""
+@pytest.mark.parametrize("switch", ["SDM_WGRAD3", "SDM_WGRAD8"])
+def test_three_tap_weight_gradient_kernel_forced(switch):
+    """The three-taps-per-workgroup weight-gradient kernels -- wgrad3_bf16_kernel (4 waves, one barrier per K-step) and the
+    phase-interleaved wgrad8x3_bf16_kernel of sdm_wgrad8.hip (8 waves, ring of four K-steps; planned for 3x3 stride-1 convs
+    once the launch is large) -- forced onto every eligible case of this file (SDM_WGRAD3=1 / SDM_WGRAD8=1; read once per
+    process -> subprocess): the 64- / 128-wide conv cases above incl. ragged channels, 32- / 16-wide maps with masked edge
+    products, concat rows, accumulation, the fused bias gradient, and the whole-network gradient goldens."""
     import subprocess
     import sys
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    env = dict(os.environ, SDM_WGRAD3="1")
+    env = dict(os.environ, **{switch: "1"})
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
                         "fwd_dgrad_wgrad or concat_input or grads_bf16_vs_reference_golden"],
                        env=env, capture_output=True, text=True, timeout=900)
@@ -359,3 +361,71 @@ def test_bf16_training_soak_follows_fp32(dev):
         assert sum(h[-15:]) / 15 < 0.6 * sum(h[:5]) / 5, (name, h[:5], h[-15:])
     a, b = sum(curves["fp32"][-15:]) / 15, sum(curves["bf16"][-15:]) / 15
     assert abs(a - b) <= 0.10 * a, (a, b)
+
+
+def test_adam_writes_the_bf16_weight_copies(dev, O):
+    """bf16 training: after the first step the fused Adam keeps the bf16 weight copies (plain and transposed) itself
+    (FusedAdam.adopt_bf16_copies, sdm_adam_job.w16 / w16t) -- every cached copy equals the cast of its fp32 master bit for
+    bit after further steps, the cast launches are gone from the step, the training trajectory is the one of the re-casting
+    path, and a writer the copies do not follow (a second optimizer, torch in-place updates) sends them back to re-casting."""
+    import degraders as D
+    from models import custom_layers as CL
+    from models.U_Net import U_Net
+    from sdm_hip import lib, ops
+    from sdm_hip.trainer import DiffusionTrainer, FusedAdam
+    cfg = O.full_cfg(dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=32, cond_dim=3, num_layers=2,
+                          attn_layers=[1], num_heads=2, dim_per_head=16, min_channel=96, max_channel=160))   # ragged 64-blocks
+    P = O.seeded_params(cfg, seed=3, gain=1.8)
+    sched = D.CosineNoiseDegradation(1000)
+    g = torch.Generator().manual_seed(2)
+    data = [(torch.randn(4, 3, 16, 16, generator=g).cuda(), torch.eye(3)[torch.randint(0, 3, (4,), generator=g)].cuda(),
+             torch.randn(4, 3, 16, 16, generator=g).cuda(), torch.randint(1, 1000, (4,), generator=g).cuda()) for _ in range(4)]
+
+    def run(adopt):
+        net = U_Net(**cfg)
+        net.load_state_dict(P, strict=True)
+        net = net.cuda()
+        tr = DiffusionTrainer(net, sched, lr=1e-3, train_dtype=BF, bucket_mb=0.05)
+        tr.adopt_bf16 = adopt
+        losses, launches = [], []
+        for x0, lab, eps, t in data:
+            l0 = lib.launch_count()
+            losses.append(float(tr.step(x0, lab, eps=eps, t=t)))
+            launches.append(lib.launch_count() - l0)
+        torch.cuda.synchronize()
+        return net, tr, losses, launches
+
+    net0, tr0, l0, n0 = run(False)
+    net1, tr1, l1, n1 = run(True)
+    assert tr1.opt.adopted > 10 and tr0.opt.adopted == 0
+    # same arithmetic (the copies hold the same bits either way); what is left is the summation order of the atomics
+    assert all(abs(a - b) <= 1e-3 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
+    # (Adam turns a gradient entry that is pure rounding noise into a +-lr step of random sign, so single entries may sit
+    # several lr apart after four steps; the bulk may not)
+    far = tot = 0
+    for k, v in net0.state_dict().items():
+        if v.dtype.is_floating_point:
+            far += int(((v - net1.state_dict()[k]).abs() > 0.5e-3).sum())
+            tot += v.numel()
+    assert far / tot < 0.01, (far, tot)
+    assert n1[3] < n0[3] - tr1.opt.adopted + 2, (n0, n1)       # one cast launch per copy and step is gone
+    checked = 0
+    for mod in net1.modules():
+        for key, hit in mod.__dict__.get("_bf16_cache", {}).items():
+            if key not in ("taps", "w", "taps_t", "wt"):
+                continue
+            assert len(hit) == 3, (type(mod).__name__, key)
+            src = mod.taps() if key.startswith("taps") else (mod.weight.detach()[None] if key == "wt" else mod.weight.detach())
+            want = ops.to_bf16_t(src.contiguous(), pad_to=8 if key == "taps_t" else 1) if key in ("taps_t", "wt") else ops.to_bf16(src)
+            assert torch.equal(hit[1].view(torch.int16), want.view(torch.int16)), (type(mod).__name__, key)
+            checked += 1
+    assert checked == tr1.opt.adopted
+    # a writer the copies do not follow: they fall back to re-casting (and are right again)
+    conv = next(m for m in net1.modules() if isinstance(m, CL.TapConv) and "taps" in m.__dict__.get("_bf16_cache", {}))
+    other = FusedAdam(net1, tr1.items, lr=1e-3)
+    tr1.flat.normal_()
+    other.step()
+    torch.cuda.synchronize()
+    fresh = conv.taps_for(CL.RunCtx(True, bf16=True))
+    assert torch.equal(fresh.view(torch.int16), ops.to_bf16(conv.taps()).view(torch.int16))
+    assert len(conv.__dict__["_bf16_cache"]["taps"]) == 2

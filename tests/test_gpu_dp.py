@@ -184,3 +184,59 @@ def test_bench_two_rank_rehearsal_reports_multi_gpu_fields(tmp_path):
               "c4_bf16_steps_per_s"):
         assert isinstance(m[k], float) and m[k] == m[k], k
     assert m["c4_steps_per_s"] > 0 and "cpu_baseline" not in out
+
+
+def test_library_owned_communicator_one_rank():
+    """sdm_dp_* on the one GPU (RCCL communicator of size 1, owned by libsdm_hip.so): fp32 wire leaves the bucket as it is,
+    the bf16 wire rounds it (pack -> fp32 "sum" of the owner's unrounded values -> one rounding -> unpack), odd lengths and
+    the staging growth included; a dead handle is refused; DiffusionTrainer(dp_backend="sdm") steps exactly like the default."""
+    _setup_paths()
+    import degraders as D
+    from models.U_Net import U_Net
+    from oracle import unet_oracle as O
+    from sdm_hip import dp, lib
+    from sdm_hip.trainer import DiffusionTrainer
+    assert lib.call("sdm_dp_available") > 20000
+    ex = dp.SdmExchange(None, "f32")
+    assert (ex.world, ex.rank) == (1, 0)
+    assert lib.call("sdm_dp_world", ex.handle) == 1 and lib.call("sdm_dp_rank", ex.handle) == 0
+    g = torch.Generator().manual_seed(9)
+    for n in (8, 1003, 160000, 5_000_001):
+        x = (torch.randn(n + 4, generator=g) * 3).cuda()[4 if n != 1003 else 3:]     # 16-byte aligned (not 64); one odd start
+        y = x.clone()
+        ex.all_reduce(y).wait()
+        torch.cuda.synchronize()
+        assert torch.equal(y, x), n
+        ex.wire = "bf16"
+        ex.all_reduce(y).wait()
+        torch.cuda.synchronize()
+        assert torch.equal(y, x.to(torch.bfloat16).float()), n
+        ex.wire = "f32"
+    ex.check()
+    with pytest.raises(lib.SdmError, match="null buffer"):
+        lib.call("sdm_dp_allreduce_bucket", ex.handle, None, 8, 0, 0, None)
+    h = ex.handle
+    ex.close()
+    assert lib.raw("sdm_dp_world")(h) == -1 and "communicator" in lib.last_error()
+
+    cfg = O.full_cfg(NARROW)
+    x0, eps, t, lab = _data()
+    states = []
+    for kw in ({}, {"dp_backend": "sdm"}, {"dp_backend": "sdm", "dp_wire": "bf16"}):
+        net = U_Net(**cfg)
+        net.load_state_dict(O.seeded_params(cfg, seed=3, gain=1.8), strict=True)
+        net = net.cuda()
+        tr = DiffusionTrainer(net, D.CosineNoiseDegradation(1000), lr=2e-3, bucket_mb=1, **kw)
+        loss = float(tr.step(x0[0].cuda(), lab[0].cuda(), eps=eps[0].cuda(), t=t[0].cuda()))
+        torch.cuda.synchronize()
+        tr.exchange.check()
+        states.append((loss, {k: v.detach().clone() for k, v in net.state_dict().items()}))
+        tr.exchange.close()
+    assert all(abs(s[0] - states[0][0]) <= 1e-5 * abs(states[0][0]) for s in states)
+    for k, v in states[0][1].items():                                  # fp32 wire, one rank: the same step up to the
+        if v.dtype.is_floating_point:                                  # summation order of the backward's atomics
+            assert float((v - states[1][1][k]).abs().mean()) < 0.05 * 2e-3, k
+    # bf16 wire: gradients rounded to bf16 before Adam; the first Adam step is lr * g / (|g| + eps): rounding g moves it by
+    # at most ~2^-9 relative of lr
+    worst = max(float((v - states[2][1][k]).abs().max()) for k, v in states[0][1].items() if v.dtype.is_floating_point)
+    assert worst <= 2e-3 * 2.0 ** -5, worst

@@ -7,7 +7,7 @@ import glob
 import json
 import sys
 
-KEYS = ("igemm_bf16_kernel", "colstats_combine", "transpose_bf16", "col_softmax_bf16", "attn_")
+KEYS = ("igemm_bf16_kernel", "igemm8_bf16_kernel", "colstats_combine", "transpose_bf16", "col_softmax_bf16", "attn_")
 
 
 def last_call(d, per_call):
