@@ -76,7 +76,9 @@ __device__ __forceinline__ void tr8(s16x4& v, unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
 }
 
-template <int WSH>
+// DBG (timing experiments only, results are wrong when set; tools/wgrad_ab.py with SDM_WGRAD8_DBG): bit 0 = no DMA after the
+// prologue (and no vmcnt waits), bit 1 = no fragment reads in the loop, bit 2 = no second barrier of a phase, bit 3 = no MFMAs
+template <int WSH, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void wgrad8x3_bf16_kernel(const Wgrad3Launch L) {
   const sdm_wgrad_desc& d = L.d;
   extern __shared__ __align__(16) char smem_w8[];
@@ -239,12 +241,17 @@ __global__ __launch_bounds__(512, 2) void wgrad8x3_bf16_kernel(const Wgrad3Launc
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    if (!(DBG & 8)) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+      for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        acc[sft][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kk][i]),
-                                                              __builtin_bit_cast(bf16x8, fb[kk]), acc[sft][i], 0, 0, 0);
+        for (int i = 0; i < 2; ++i)
+          acc[sft][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kk][i]),
+                                                                __builtin_bit_cast(bf16x8, fb[kk]), acc[sft][i], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(fa[kk][0]), "v"(fa[kk][1]), "v"(fb[kk]));
+    }
     __builtin_amdgcn_s_setprio(0);
     if (sft == 0 && do_bias) {          // column sums of this K-step's gradient rows (a lane: channel l & 31, 8 pixels per fragment)
 #pragma unroll
@@ -278,28 +285,29 @@ __global__ __launch_bounds__(512, 2) void wgrad8x3_bf16_kernel(const Wgrad3Launc
     const unsigned so = (unsigned)((t & (W8_NST - 1)) * W8_ST), sn = (unsigned)(((t + 1) & (W8_NST - 1)) * W8_ST);
     const bool more = t + 1 < nT, steady = t + 3 < nT;
     // phase 0
-    read_a(ICW(set), ICW(6), ICW(8), so);
-    read_b(ICW(0), so);
-    if (steady) { issue_g(); wait_steady(); }
-    else wait_vm_w8<0>();
+    if (!(DBG & 2)) { read_a(ICW(set), ICW(6), ICW(8), so); read_b(ICW(0), so); }
+    if (!(DBG & 1)) {
+      if (steady) { issue_g(); wait_steady(); }
+      else wait_vm_w8<0>();
+    }
     __builtin_amdgcn_s_barrier();
     mfma_tap(ICW(set), ICW(0));
-    __builtin_amdgcn_s_barrier();
+    if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
     // phase 1
-    read_b(ICW(1), so);
-    if (more) read_a(ICW(set ^ 1), ICW(0), ICW(3), sn);
-    if (steady) issue_x();
+    if (!(DBG & 2)) { read_b(ICW(1), so); if (more) read_a(ICW(set ^ 1), ICW(0), ICW(3), sn); }
+    if (!(DBG & 1) && steady) issue_x();
     __builtin_amdgcn_s_barrier();
     mfma_tap(ICW(set), ICW(1));
-    __builtin_amdgcn_s_barrier();
+    if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
     // phase 2
-    read_b(ICW(2), so);
-    if (more) read_a(ICW(set ^ 1), ICW(3), ICW(6), sn);
-    if (steady) wait_steady();
-    else wait_vm_w8<0>();
+    if (!(DBG & 2)) { read_b(ICW(2), so); if (more) read_a(ICW(set ^ 1), ICW(3), ICW(6), sn); }
+    if (!(DBG & 1)) {
+      if (steady) wait_steady();
+      else wait_vm_w8<0>();
+    }
     __builtin_amdgcn_s_barrier();
     mfma_tap(ICW(set), ICW(2));
-    __builtin_amdgcn_s_barrier();
+    if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
   };
   for (int t = 0; t < nT; t += 2) {
     kstep(ICW(0), t);
@@ -355,6 +363,20 @@ int sdm_launch_wgrad8x3_bf16(const Wgrad3Launch& L3, hipStream_t st) {
   }
   sdm_prof_pre(st);
   const dim3 grid(cdiv(d->M, 128) * L3.ntn * L3.splitk, 3, 1);
+  static const char* dbg_s = getenv("SDM_WGRAD8_DBG");
+  const int dbg = dbg_s ? atoi(dbg_s) : 0;
+  if (dbg && d->Wk >= 64) {
+#define W8_DBG_CASE(v)                                                                                                        \
+  case v:                                                                                                                     \
+    (void)hipFuncSetAttribute((const void*)wgrad8x3_bf16_kernel<6, v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    SDM_LAUNCH((wgrad8x3_bf16_kernel<6, v>), grid, dim3(512), lds, st, L3);                                                   \
+    break;
+    switch (dbg) {
+      W8_DBG_CASE(1) W8_DBG_CASE(2) W8_DBG_CASE(3) W8_DBG_CASE(4) W8_DBG_CASE(8) W8_DBG_CASE(9) W8_DBG_CASE(10) W8_DBG_CASE(11)
+      default: return sdm_set_error(SDM_ERR_ARG, "SDM_WGRAD8_DBG: unknown experiment %d", dbg);
+    }
+#undef W8_DBG_CASE
+  } else
   if (d->Wk >= 64) SDM_LAUNCH(wgrad8x3_bf16_kernel<6>, grid, dim3(512), lds, st, L3);
   else if (d->Wk == 32) SDM_LAUNCH(wgrad8x3_bf16_kernel<5>, grid, dim3(512), lds, st, L3);
   else SDM_LAUNCH(wgrad8x3_bf16_kernel<4>, grid, dim3(512), lds, st, L3);

@@ -175,7 +175,16 @@ def test_unet_forward_bf16_vs_golden(dev, O, case):
         y = net(x, t if cfg["time_dim"] is not None else None, cond)
     assert y.dtype == torch.float32
     r = rel(y, T(g["y"]))
-    assert r < 1e-2, r
+    assert r < 1e-2, r                                          # outer bound: the reference's fp32 output
+    # derived gate: the oracle's bf16-storage mode and its jittered twin (tests/bf16_gates.py)
+    import bf16_gates as BG
+    P = O.seeded_params(cfg, seed=3, gain=float(g["gain"]))
+    xx, tt = T(g["x"]), (T(g["t"]) if cfg["time_dim"] is not None else None)
+    cc = T(g["cond"]) if "cond" in g.files else None
+    with torch.no_grad():
+        yb = O.unet_forward(P, cfg, xx, tt, cc, storage=torch.bfloat16)
+        ytw = O.unet_forward(P, cfg, xx, tt, cc, storage=O.Bf16Storage().floor_twin(jitter=BG.TWIN_JITTER))
+    BG.check_forward(y, yb, T(g["y"]), ytw, what=case)
     net.set_inference_dtype(torch.float32)                      # and back: the fp32 path is untouched
     with torch.no_grad():
         y32 = net(x, t if cfg["time_dim"] is not None else None, cond)
@@ -192,11 +201,15 @@ def test_standard_architecture_bf16_vs_oracle(dev, O):
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(2, 3, 64, 64, generator=g)
     t = torch.tensor([753, 12])
+    import bf16_gates as BG
     with torch.no_grad():
         ref = O.unet_forward(P, cfg, x, t)
         y = net(x.cuda(), t.cuda())
+        yb = O.unet_forward(P, cfg, x, t, storage=torch.bfloat16)
+        ytw = O.unet_forward(P, cfg, x, t, storage=O.Bf16Storage().floor_twin(jitter=BG.TWIN_JITTER))
     r = rel(y, ref)
     assert r < 1e-2, r
+    BG.check_forward(y, yb, ref, ytw, what="standard 64x64 N=2")
 
 
 @pytest.mark.parametrize("use_graph", [False, True])

@@ -260,6 +260,16 @@ def test_unet_grads_bf16_vs_reference_golden(dev, O, case):
     errs.sort()
     print(f"bf16 grads vs fp32 [{case}]: median {errs[len(errs) // 2][0]:.2e}, worst {errs[-1][0]:.2e} ({errs[-1][1]})")
     assert not bad, bad[:10]
+    # derived gate: the oracle's bf16-storage TRAINING mode, its jittered twin and fp32 (tests/bf16_gates.py)
+    import bf16_gates as BG
+    xx, tt = T(z["x"]), (T(z["t"]) if cfg.get("time_dim") is not None else None)
+    cc = T(z["cond"]) if "cond" in z.files else None
+    lb, gb = BG.oracle_grads(O, P, cfg, xx, tt, cc, T(z["target"]), O.Bf16Storage(train=True))
+    _, gtw = BG.oracle_grads(O, P, cfg, xx, tt, cc, T(z["target"]), O.Bf16Storage(train=True).floor_twin(jitter=BG.TWIN_JITTER))
+    l32, g32 = BG.oracle_grads(O, P, cfg, xx, tt, cc, T(z["target"]), None)
+    assert abs(float(loss) - lb) <= 3 * max(abs(lb - l32), 5e-5 * abs(l32)), (float(loss), lb, l32)
+    hip = {k: grads[names[k]] for k in names if names[k] in grads}
+    BG.check_grads(hip, gb, g32, gtw, skip=lambda k: ".conv_block_" in k and k.endswith("conv_layer.0.bias"), what=case)
     assert errs[len(errs) // 2][0] < 1.5e-2
 
 

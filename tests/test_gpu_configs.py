@@ -177,19 +177,22 @@ def test_c3_ddim_cfg_bf16_128(dev, O, use_graph):
     labels = torch.eye(10)[[4, 9]]
     sched = O.CosineSchedule(1000)
     steps = O.ddim_steps(1, 1000, 400)                                 # [1000, 600, 200, 1]
-    x = xT.clone()
-    x0 = None
-    with torch.no_grad():
-        for i, s in enumerate(steps):
-            t = torch.full((n,), s)
-            e_c = O.unet_forward(P, cfg, x, t, labels)
-            e_u = O.unet_forward(P, cfg, x, t, torch.zeros_like(labels))
-            e = e_u + w * (e_c - e_u)
-            ab = sched.alpha_bar(torch.tensor([s]))
-            x0 = (x - (1 - ab) ** 0.5 * e) / ab ** 0.5
-            if i + 1 < len(steps):
-                abn = sched.alpha_bar(torch.tensor([steps[i + 1]]))
-                x = abn ** 0.5 * x0 + (1 - abn) ** 0.5 * e
+    def oracle_run(storage):
+        x = xT.clone()
+        x0 = None
+        with torch.no_grad():
+            for i, s in enumerate(steps):
+                t = torch.full((n,), s)
+                e_c = O.unet_forward(P, cfg, x, t, labels, storage=storage)
+                e_u = O.unet_forward(P, cfg, x, t, torch.zeros_like(labels), storage=storage)
+                e = e_u + w * (e_c - e_u)
+                ab = sched.alpha_bar(torch.tensor([s]))
+                x0 = (x - (1 - ab) ** 0.5 * e) / ab ** 0.5
+                if i + 1 < len(steps):
+                    abn = sched.alpha_bar(torch.tensor([steps[i + 1]]))
+                    x = abn ** 0.5 * x0 + (1 - abn) ** 0.5 * e
+        return x0
+    x0 = oracle_run(None)
     quiet = lambda *a, **k: None
     out32 = S.ddim_sampling(net, D.CosineNoiseDegradation(1000), xT.cuda(), 1, 1000, None, labels.cuda(), 400, "cuda", quiet,
                             use_graph=use_graph, cfg_scale=w)
@@ -199,6 +202,11 @@ def test_c3_ddim_cfg_bf16_128(dev, O, use_graph):
                             use_graph=use_graph, cfg_scale=w)
     assert rel(out16, x0) < 1e-2, rel(out16, x0)
     assert rel(out16, out32) > 1e-6            # the bf16 path really ran
+    if use_graph:
+        # derived gate (tests/bf16_gates.py; one extra oracle run: the bf16-storage mode of the same guided sampler -- U-Net
+        # outputs in storage mode, the sampler state fp32 as in the HIP path; floor = the model's own bf16 error / 4)
+        import bf16_gates as BG
+        BG.check_forward(out16, oracle_run(torch.bfloat16), x0, None, what="C3 guided DDIM, 4 U-Net passes")
 
 
 # ------------------------------------------------------------------------------------------------ C4
@@ -288,6 +296,14 @@ def test_c4_training_step_128_bf16(dev, O):
     loss, grads = net.loss_and_grads(x_t, t.cuda(), None, eps.cuda())
     assert abs(float(loss) - float(ref_loss)) < 1e-2 * max(1.0, abs(float(ref_loss)))
     assert _check_grads_bf16(O, cfg, net, grads, ref_g) == 148 - 16
+    # derived gate (tests/bf16_gates.py): the oracle's bf16-storage training mode on the same batch (one extra oracle pass)
+    import bf16_gates as BG
+    x_in = O.q_sample(O.CosineSchedule(1000), x0, t, eps)
+    lb, gb = BG.oracle_grads(O, P, cfg, x_in, t, None, eps, O.Bf16Storage(train=True))
+    assert abs(float(loss) - lb) <= 3 * max(abs(lb - float(ref_loss)), 5e-5 * abs(float(ref_loss))), (float(loss), lb, float(ref_loss))
+    dead = set(O.dead_param_names(cfg))
+    hip = {k: grads[p] for k, p in net.named_parameters() if k not in dead}
+    BG.check_grads(hip, gb, ref_g, None, skip=lambda k: ".conv_block_" in k and k.endswith("conv_layer.0.bias"), what="C4 128x128 N=2")
 
 
 def test_c5_sr_training_step_256_bf16(dev, O):
@@ -304,6 +320,14 @@ def test_c5_sr_training_step_256_bf16(dev, O):
     # ONE image: a weight gradient averages over a single sample, and the tensors furthest from the loss (down path, ~40
     # bf16 roundings of the activation gradient behind them) reach 2.7e-2 (median 6e-3); C4 at N=2 holds 2e-2
     assert _check_grads_bf16(O, cfg, net, grads, ref_g, lim=3e-2) == 148 - 16
+    # derived gate (tests/bf16_gates.py): the oracle's bf16-storage training mode on the same SR batch (one extra oracle pass)
+    import bf16_gates as BG
+    xo, to = O.sr_batch(O.CosineSchedule(1000), x0, t, eps, 64, 256, 100)
+    lb, gb = BG.oracle_grads(O, P, cfg, xo, t, None, to, O.Bf16Storage(train=True))
+    assert abs(float(loss) - lb) <= 3 * max(abs(lb - float(ref_loss)), 5e-5 * abs(float(ref_loss))), (float(loss), lb, float(ref_loss))
+    dead = set(O.dead_param_names(cfg))
+    hip = {k: grads[p] for k, p in net.named_parameters() if k not in dead}
+    BG.check_grads(hip, gb, ref_g, None, skip=lambda k: ".conv_block_" in k and k.endswith("conv_layer.0.bias"), what="C5 SR 256x256 N=1")
 
 
 # ------------------------------------------------------------------------------------------------ full batch sizes: properties
