@@ -132,7 +132,10 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
   const bf16_t* pA[2][2];
   int stA[2][2];
   const bf16_t* pB[2][2];
-  int tpA[2] = {0, 0}, kcA[2] = {0, 0}, tpB[2] = {0, 0}, kcB[2] = {0, 0};
+  // K walk of a tap: K-tiles rot, rot + 1, .., kch - 1, 0, .., rot - 1 (rot = 0 unless L.krot: see BfLaunch)
+  const int rot = L.krot ? tile_id % kch : 0;
+  int tpA[2] = {0, 0}, kcA[2] = {rot, rot}, cnA[2] = {0, 0}, tpB[2] = {0, 0}, kcB[2] = {rot, rot}, cnB[2] = {0, 0};
+  const bool one_src = kch0 >= kch;
   // A half h: pointers of the segment (tap tp, from K-tile kc of that tap)
   auto seg_a = [&](auto hc, int tp, int kc) {
     constexpr int h = decltype(hc)::value;
@@ -155,10 +158,10 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
     for (int i = 0; i < 2; ++i) {
       int n = n0 + h * 128 + i * 64 + srow;
       n = n < N ? n : N - 1;
-      pB[h][i] = bw + (long long)s_tap[2 * SDM_MAX_TAPS] * d.b_tap_stride + (long long)n * d.ldb + cc8;
+      pB[h][i] = bw + (long long)s_tap[2 * SDM_MAX_TAPS] * d.b_tap_stride + (long long)n * d.ldb + cc8 + (rot << 6);
     }
-  seg_a(IC8(0), 0, 0);
-  seg_a(IC8(1), 0, 0);
+  seg_a(IC8(0), 0, rot);
+  seg_a(IC8(1), 0, rot);
 
   char* lds_w = smem8 + wave * 1024;
   // staging s = 4 T + j : j = 0 B half 0, 1 A half 0, 2 B half 1, 3 A half 1 ; slot = s & 7
@@ -169,19 +172,34 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
       __builtin_amdgcn_global_load_lds((glb_ptr)pB[h][0], (lds_ptr)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((glb_ptr)pB[h][1], (lds_ptr)(dst + 8192), 16, 0, 0);
       long long step = 64;
-      if (++kcB[h] == kch) {                               // next tap's weight slice
-        kcB[h] = 0;
+      const int kc_last = kcB[h];
+      if (++cnB[h] == kch) {                               // next tap's weight slice, from its K-tile rot on
+        cnB[h] = 0;
+        kcB[h] = rot;
         const int t = tpB[h]++;
-        if (t + 1 < ntap) step = (long long)(s_tap[2 * SDM_MAX_TAPS + t + 1] - s_tap[2 * SDM_MAX_TAPS + t]) * d.b_tap_stride - (K - 64);
+        step = (rot - kc_last) * 64;
+        if (t + 1 < ntap) step += (long long)(s_tap[2 * SDM_MAX_TAPS + t + 1] - s_tap[2 * SDM_MAX_TAPS + t]) * d.b_tap_stride;
+      } else if (++kcB[h] == kch) {                        // wrap inside the tap
+        kcB[h] = 0;
+        step = 64 - K;
       }
       pB[h][0] += step;
       pB[h][1] += step;
     } else {
       __builtin_amdgcn_global_load_lds((glb_ptr)pA[h][0], (lds_ptr)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((glb_ptr)pA[h][1], (lds_ptr)(dst + 8192), 16, 0, 0);
-      if (++kcA[h] == kch) {
+      if (++cnA[h] == kch) {
+        cnA[h] = 0;
+        kcA[h] = rot;
+        if (++tpA[h] < ntap) seg_a(IC8(h), tpA[h], rot);
+      } else if (++kcA[h] == kch) {                        // wrap inside the tap
         kcA[h] = 0;
-        if (++tpA[h] < ntap) seg_a(IC8(h), tpA[h], 0);
+        if (one_src) {                                     // (stA is 64 for a row inside the image, 0 for the zero chunk)
+          pA[h][0] -= (kch - 1) * stA[h][0];
+          pA[h][1] -= (kch - 1) * stA[h][1];
+        } else {
+          seg_a(IC8(h), tpA[h], 0);
+        }
       } else if (kcA[h] == kch0) {
         seg_a(IC8(h), tpA[h], kcA[h]);                     // the second concatenated source starts
       } else {

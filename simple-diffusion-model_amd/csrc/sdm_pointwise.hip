@@ -880,19 +880,36 @@ __global__ __launch_bounds__(256) void linear_small_bwd_dx_kernel(const float* _
   atomicAdd(&dx[(long long)m * lddx + k], a);
 }
 
+// dw[o][k] += sum_m dy[m][o] * x[m][k]; db[o] += sum_m dy[m][o]   (M = batch rows of the embedding: 4 .. 256)
+// One output row per workgroup (O x K / 256 workgroups: the launch is a chain of memory round trips, so parallelism is what
+// it needs), the batch rows taken EIGHT AT A TIME with all sixteen loads issued before the first use: a round trip per eight
+// rows instead of one per row (the rolled loop took 12.6 us at M = 32 at best and 37-47 us inside a C4 / C5 step; a variant with
+// 16 output rows per workgroup and the dy rows in LDS was SLOWER, 74 us: too few workgroups -- profiles/r04_c4_bf16_train_kernel_stats.csv).
 __global__ __launch_bounds__(256) void linear_small_bwd_dw_kernel(const float* __restrict__ dy, long long lddy,
                                                                   const float* __restrict__ x, long long ldx,
                                                                   float* __restrict__ dw, float* __restrict__ db, int M,
                                                                   int K, int O) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int o = blockIdx.y;
+  const int kk = k < K ? k : K - 1;
   float a = 0.f, bsum = 0.f;
-  for (int m = 0; m < M; ++m) {
-    const float d = dy[(long long)m * lddy + o];
-    bsum += d;
-    if (k < K) a = fmaf(d, x[(long long)m * ldx + k], a);
+  const float old = k < K ? dw[(long long)o * K + k] : 0.f;       // in flight under the reduction
+  for (int m0 = 0; m0 < M; m0 += 8) {
+    float d[8], xv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + i < M ? m0 + i : M - 1;
+      d[i] = dy[(long long)m * lddy + o];
+      xv[i] = x[(long long)m * ldx + kk];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float di = m0 + i < M ? d[i] : 0.f;
+      bsum += di;
+      a = fmaf(di, xv[i], a);
+    }
   }
-  if (k < K) dw[(long long)o * K + k] += a;
+  if (k < K) dw[(long long)o * K + k] = old + a;
   if (db && k == 0) db[o] += bsum;
 }
 

@@ -28,7 +28,7 @@ struct Feed {
   static constexpr int ROWS_PER_PASS = NT / 8;
   const char* base;
   long long win, lane_off;
-  int pitch;
+  int pitch, piece, rpp, rot;
   char* smem;
   unsigned lds0;
   int tid, wave, nst;
@@ -36,8 +36,10 @@ struct Feed {
   f32x4 acc;
   __device__ __forceinline__ const char* src_of(int s, int p) const {
     // staging s covers 128 rows x 128 B: K-tile (s & 7) of row block (s >> 3), wrapped into the window
-    const long long blk = ((long long)(s >> 3) * 128 * pitch) % win;
-    return base + blk + (long long)(s & 7) * 128 + (long long)p * ROWS_PER_PASS * pitch + lane_off;
+    // a staging covers (16384 / piece) rows x `piece` contiguous bytes; (1024 / piece) stagings walk a row block's 1 KB of k
+    const int per_blk = 1024 / piece, rows = SLOT / piece;
+    const long long blk = ((long long)(s / per_blk) * rows * pitch) % win;
+    return base + blk + (long long)((s + rot) % per_blk) * piece + (long long)p * rpp * pitch + lane_off;
   }
   template <int Q>
   __device__ __forceinline__ void issue(int s) {
@@ -81,7 +83,7 @@ struct Feed {
 };
 
 template <int MODE, int NT, int DEPTH>
-__global__ __launch_bounds__(NT) void feed(const char* __restrict__ src, long long win, int nst, float* __restrict__ sink, int pitch) {
+__global__ __launch_bounds__(NT) void feed(const char* __restrict__ src, long long win, int nst, float* __restrict__ sink, int pitch, int piece) {
   extern __shared__ __align__(16) char smem[];
   static_assert(DEPTH == 5, "unrolled for 5 stagings in flight");
   Feed<MODE, NT, DEPTH> f;
@@ -89,8 +91,8 @@ __global__ __launch_bounds__(NT) void feed(const char* __restrict__ src, long lo
   f.wave = __builtin_amdgcn_readfirstlane(f.tid >> 6);
   f.base = src + (long long)blockIdx.x * win;
   f.win = win;
-  f.pitch = pitch;
-  f.lane_off = (long long)(f.tid >> 3) * pitch + (f.tid & 7) * 16;   // (row of a pass, 16-byte chunk)
+  f.pitch = pitch; f.piece = piece % 100000; f.rpp = NT / (f.piece / 16); f.rot = piece >= 100000 ? (int)blockIdx.x : 0; piece = f.piece;
+  f.lane_off = (long long)(f.tid / (piece / 16)) * pitch + (f.tid % (piece / 16)) * 16;   // (row of a pass, 16-byte chunk)
   f.smem = smem;
   f.lds0 = (unsigned)(uintptr_t)(lds_ptr)smem;
   f.nst = nst;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(NT) void feed(const char* __restrict__ src, long lo
 }
 
 template <int MODE, int NT>
-static void run(const char* name, const char* src, long long win, int nst, float* sink, int ncu, int pitch) {
+static void run(const char* name, const char* src, long long win, int nst, float* sink, int ncu, int pitch, int piece) {
   auto k = feed<MODE, NT, 5>;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * SLOT);
   hipEvent_t a, b;
@@ -118,7 +120,7 @@ static void run(const char* name, const char* src, long long win, int nst, float
   (void)hipEventCreate(&b);
   for (int rep = 0; rep < 3; ++rep) {
     (void)hipEventRecord(a, 0);
-    hipLaunchKernelGGL(k, dim3(ncu), dim3(NT), 8 * SLOT, 0, src, win, nst, sink, pitch);
+    hipLaunchKernelGGL(k, dim3(ncu), dim3(NT), 8 * SLOT, 0, src, win, nst, sink, pitch, piece);
     (void)hipEventRecord(b, 0);
     (void)hipEventSynchronize(b);
     float ms = 0;
@@ -144,14 +146,16 @@ struct Deep {
   static constexpr int PER = SLOT / (NT * 16), ROWS_PER_PASS = NT / 8;
   const char* base;
   long long win, lane_off;
-  int pitch;
+  int pitch, piece, rpp, rot;
   unsigned lds0;
   int tid, nst;
   f32x4 regs[DEPTH][PER];
   f32x4 acc;
   __device__ __forceinline__ const char* src_of(int s, int p) const {
-    const long long blk = ((long long)(s >> 3) * 128 * pitch) % win;
-    return base + blk + (long long)(s & 7) * 128 + (long long)p * ROWS_PER_PASS * pitch + lane_off;
+    // a staging covers (16384 / piece) rows x `piece` contiguous bytes; (1024 / piece) stagings walk a row block's 1 KB of k
+    const int per_blk = 1024 / piece, rows = SLOT / piece;
+    const long long blk = ((long long)(s / per_blk) * rows * pitch) % win;
+    return base + blk + (long long)((s + rot) % per_blk) * piece + (long long)p * rpp * pitch + lane_off;
   }
   template <int Q>
   __device__ __forceinline__ void issue(int s) {
@@ -182,14 +186,14 @@ struct Deep {
   }
 };
 template <int NT, int DEPTH>
-__global__ __launch_bounds__(NT) void feed_deep(const char* __restrict__ src, long long win, int nst, float* __restrict__ sink, int pitch) {
+__global__ __launch_bounds__(NT) void feed_deep(const char* __restrict__ src, long long win, int nst, float* __restrict__ sink, int pitch, int piece) {
   extern __shared__ __align__(16) char smem[];
   Deep<NT, DEPTH> f;
   f.tid = threadIdx.x;
   f.base = src + (long long)blockIdx.x * win;
   f.win = win;
-  f.pitch = pitch;
-  f.lane_off = (long long)(f.tid >> 3) * pitch + (f.tid & 7) * 16;
+  f.pitch = pitch; f.piece = piece % 100000; f.rpp = NT / (f.piece / 16); f.rot = piece >= 100000 ? (int)blockIdx.x : 0; piece = f.piece;
+  f.lane_off = (long long)(f.tid / (piece / 16)) * pitch + (f.tid % (piece / 16)) * 16;
   f.lds0 = (unsigned)(uintptr_t)(lds_ptr)smem;
   f.nst = nst;
   f.acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(NT) void feed_deep(const char* __restrict__ src, lo
   if (f.acc[0] + f.acc[1] + f.acc[2] + f.acc[3] == 12345.678f) sink[blockIdx.x] = f.acc[0];
 }
 template <int NT, int DEPTH>
-static void run_deep(const char* name, const char* src, long long win, int nst, float* sink, int ncu, int pitch) {
+static void run_deep(const char* name, const char* src, long long win, int nst, float* sink, int ncu, int pitch, int piece) {
   auto k = feed_deep<NT, DEPTH>;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT);
   hipEvent_t a, b;
@@ -208,7 +212,7 @@ static void run_deep(const char* name, const char* src, long long win, int nst, 
   (void)hipEventCreate(&b);
   for (int rep = 0; rep < 3; ++rep) {
     (void)hipEventRecord(a, 0);
-    hipLaunchKernelGGL(k, dim3(ncu), dim3(NT), 4 * SLOT, 0, src, win, nst, sink, pitch);
+    hipLaunchKernelGGL(k, dim3(ncu), dim3(NT), 4 * SLOT, 0, src, win, nst, sink, pitch, piece);
     (void)hipEventRecord(b, 0);
     (void)hipEventSynchronize(b);
     float ms = 0;
@@ -224,6 +228,8 @@ int main(int argc, char** argv) {
   const int nst = argc > 1 ? atoi(argv[1]) : 576;          // 576 stagings of 16 KB = 72 K-tiles of a 256x256 tile (9 MB per CU)
   const long long win = (long long)(argc > 2 ? atoi(argv[2]) : 512) * 1024;
   const int pitch = argc > 3 ? atoi(argv[3]) : 1024;
+  const int rotate = argc > 5 ? atoi(argv[5]) : 0;       // 1: every workgroup starts its k walk at a different 128-B column
+  const int piece = (argc > 4 ? atoi(argv[4]) : 128) + (rotate ? 100000 : 0);
   int ncu = 256;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, 0) == hipSuccess) ncu = prop.multiProcessorCount;
@@ -232,21 +238,21 @@ int main(int argc, char** argv) {
   const size_t total = (size_t)ncu * win + (2 << 20);
   if (hipMalloc(&src, total) != hipSuccess || hipMalloc(&sink, ncu * 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
   (void)hipMemset(src, 1, total);
-  printf("%d CUs, %d stagings of 16 KB per workgroup, window %lld KB per workgroup, row pitch %d B, one barrier pair per staging\n",
-         ncu, nst, win / 1024, pitch);
-  run<0, 512>("LDS-DMA, 8 waves", src, win, nst, sink, ncu, pitch);
-  run<1, 512>("register-staged + ds_write_b128, 8 waves", src, win, nst, sink, ncu, pitch);
-  run<2, 512>("alternating DMA / register-staged, 8 waves", src, win, nst, sink, ncu, pitch);
-  run<0, 256>("LDS-DMA, 4 waves", src, win, nst, sink, ncu, pitch);
-  run<1, 256>("register-staged + ds_write_b128, 4 waves", src, win, nst, sink, ncu, pitch);
-  run<2, 256>("alternating DMA / register-staged, 4 waves", src, win, nst, sink, ncu, pitch);
-  run_deep<512, 3>("register-staged, 8 waves, 3 in flight", src, win, nst, sink, ncu, pitch);
-  run_deep<512, 5>("register-staged, 8 waves, 5 in flight", src, win, nst, sink, ncu, pitch);
-  run_deep<512, 8>("register-staged, 8 waves, 8 in flight", src, win, nst, sink, ncu, pitch);
-  run_deep<512, 12>("register-staged, 8 waves, 12 in flight", src, win, nst, sink, ncu, pitch);
-  run_deep<512, 16>("register-staged, 8 waves, 16 in flight", src, win, nst, sink, ncu, pitch);
-  run_deep<256, 4>("register-staged, 4 waves, 4 in flight", src, win, nst, sink, ncu, pitch);
-  run_deep<256, 8>("register-staged, 4 waves, 8 in flight", src, win, nst, sink, ncu, pitch);
-  run_deep<256, 12>("register-staged, 4 waves, 12 in flight", src, win, nst, sink, ncu, pitch);
+  printf("%d CUs, %d stagings of 16 KB per workgroup, window %lld KB per workgroup, row pitch %d B, %d contiguous bytes per row, k walk rotated per workgroup: %d\n",
+         ncu, nst, win / 1024, pitch, piece % 100000, rotate);
+  run<0, 512>("LDS-DMA, 8 waves", src, win, nst, sink, ncu, pitch, piece);
+  run<1, 512>("register-staged + ds_write_b128, 8 waves", src, win, nst, sink, ncu, pitch, piece);
+  run<2, 512>("alternating DMA / register-staged, 8 waves", src, win, nst, sink, ncu, pitch, piece);
+  run<0, 256>("LDS-DMA, 4 waves", src, win, nst, sink, ncu, pitch, piece);
+  run<1, 256>("register-staged + ds_write_b128, 4 waves", src, win, nst, sink, ncu, pitch, piece);
+  run<2, 256>("alternating DMA / register-staged, 4 waves", src, win, nst, sink, ncu, pitch, piece);
+  run_deep<512, 3>("register-staged, 8 waves, 3 in flight", src, win, nst, sink, ncu, pitch, piece);
+  run_deep<512, 5>("register-staged, 8 waves, 5 in flight", src, win, nst, sink, ncu, pitch, piece);
+  run_deep<512, 8>("register-staged, 8 waves, 8 in flight", src, win, nst, sink, ncu, pitch, piece);
+  run_deep<512, 12>("register-staged, 8 waves, 12 in flight", src, win, nst, sink, ncu, pitch, piece);
+  run_deep<512, 16>("register-staged, 8 waves, 16 in flight", src, win, nst, sink, ncu, pitch, piece);
+  run_deep<256, 4>("register-staged, 4 waves, 4 in flight", src, win, nst, sink, ncu, pitch, piece);
+  run_deep<256, 8>("register-staged, 4 waves, 8 in flight", src, win, nst, sink, ncu, pitch, piece);
+  run_deep<256, 12>("register-staged, 4 waves, 12 in flight", src, win, nst, sink, ncu, pitch, piece);
   return 0;
 }
