@@ -1289,8 +1289,6 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
   const bool xs = fast && !(xs_s && xs_s[0] == '0');
   static const char* pp_s = getenv("SDM_BF16_PP");         // 8-wave tiles: ping-pong of the two 4-wave halves ("0": off)
   L.pp = (pp_s && pp_s[0] == '1') ? 1 : 0;
-  static const char* krot_s = getenv("SDM_BF16_KROT");      // igemm8: per-workgroup rotation of the K walk ("1": on)
-  L.krot = (krot_s && krot_s[0] == '1') ? 1 : 0;
   if (cfg == 0) rc = fast ? (xs ? launch_bf<128, 128, 2, 2, 2, true, true>(L, ntm, st) : launch_bf<128, 128, 2, 2, 2, true>(L, ntm, st))
                           : launch_bf<128, 128, 2, 2, 2, false>(L, ntm, st);
   else if (cfg == 1) {

@@ -93,11 +93,14 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(const WgradBfL
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, h = lane >> 5;
-  const int ntiles_ = gridDim.x / L.splitk;
-  const int wg_ = xcd_contiguous_wg(blockIdx.x, gridDim.x);
+  // 1-D grid of (pixel slice x tile) x taps: the taps of one (slice, tile) read the same gradient rows and activation rows a
+  // pixel / an image row apart, so they are neighbours of one XCD's contiguous run and meet in one L2 (as separate grid rows
+  // every tap streamed its operands from HBM: 3.0x algorithmic, profiles/r02_wgrad_bf16_512_tile256_pmc.json)
+  const int c_ = xcd_contiguous_wg(blockIdx.x, gridDim.x);
+  const int tp = c_ % d.ntaps, wg_ = c_ / d.ntaps;
+  const int ntiles_ = (gridDim.x / d.ntaps) / L.splitk;
   const int ks = wg_ / ntiles_, tile_ = wg_ - ks * ntiles_;
   const int tile_n = tile_ % L.ntn, tile_m = tile_ / L.ntn;
-  const int tp = blockIdx.y;
   const int m0 = tile_m * BT, n0 = tile_n * BT;
   const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
   const bf16_t* g0 = (const bf16_t*)d.g.p0 + b0 * d.g_bs0 + b1 * d.g_bs1;
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(const WgradBfL
 template <int BT, int WM, int WN, int NBUF, bool FASTP>
 static int launch_wgrad_bf16(const WgradBfLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * NBUF * BKP * 2 * BT;
-  dim3 grid(ntm * L.ntn * L.splitk, L.d.ntaps, L.d.batch);
+  dim3 grid(ntm * L.ntn * L.splitk * L.d.ntaps, 1, L.d.batch);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)wgrad_bf16_kernel<BT, WM, WN, NBUF, FASTP>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -366,11 +369,12 @@ __global__ __launch_bounds__(256, 2) void wgrad3_bf16_kernel(const Wgrad3Launch 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
-  const int ntiles_ = gridDim.x / L.splitk;
-  const int wg_ = xcd_contiguous_wg(blockIdx.x, gridDim.x);
+  const int c_ = xcd_contiguous_wg(blockIdx.x, gridDim.x);    // the three kernel rows of a (slice, tile): neighbours on one XCD
+  const int dyi = c_ % 3, wg_ = c_ / 3;
+  const int ntiles_ = (gridDim.x / 3) / L.splitk;
   const int ks = wg_ / ntiles_, tile_ = wg_ - ks * ntiles_;
   const int tile_n = tile_ % L.ntn, tile_m = tile_ / L.ntn;
-  const int dyi = blockIdx.y, dy = L.dy[dyi];
+  const int dy = L.dy[dyi];
   const int m0 = tile_m * BT, n0 = tile_n * BT;
   const bf16_t* g0 = (const bf16_t*)d.g.p0;
   const bf16_t* x0 = (const bf16_t*)d.x.p0;
@@ -722,7 +726,7 @@ extern "C" int sdm_wgrad_bf16(const sdm_wgrad_desc* d, sdm_stream_t stream) {
       sdm_prof_shape(d->M, d->N, (int)P, 9, sk, 2.0 * (g_b + x_b) + 4.0 * w_b);
     }
     sdm_prof_pre(st);
-    const dim3 grid3(cdiv(d->M, 128) * L3.ntn * sk, 3, 1);
+    const dim3 grid3(cdiv(d->M, 128) * L3.ntn * sk * 3, 1, 1);
     if (d->Wk >= 64) SDM_LAUNCH(wgrad3_bf16_kernel<6>, grid3, dim3(256), lds3, st, L3);
     else if (d->Wk == 32) SDM_LAUNCH(wgrad3_bf16_kernel<5>, grid3, dim3(256), lds3, st, L3);
     else SDM_LAUNCH(wgrad3_bf16_kernel<4>, grid3, dim3(256), lds3, st, L3);

@@ -1270,13 +1270,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
-  // gridDim.x = pixel slices x tiles, slice-major behind the XCD remap: one XCD's L2 sees one contiguous range of
-  // pixels of both operands (for all tiles and, via gridDim.y, all taps) instead of every XCD streaming all of them
-  const int ntiles_ = gridDim.x / L.splitk;
-  const int wg_ = xcd_contiguous(blockIdx.x, gridDim.x);
+  // gridDim.x = (pixel slices x tiles) x taps, slice-major behind the XCD remap with the taps of a (slice, tile) as
+  // neighbours: one XCD's L2 sees one contiguous range of pixels of both operands for all tiles and all taps instead of
+  // every XCD streaming all of them (with the taps in gridDim.y they kept their XCD only when gridDim.x was a multiple of 8)
+  const int c_ = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int tp = c_ % d.ntaps, wg_ = c_ / d.ntaps;
+  const int ntiles_ = (gridDim.x / d.ntaps) / L.splitk;
   const int ks = wg_ / ntiles_, tile_ = wg_ - ks * ntiles_;
   const int tile_n = tile_ % L.ntn, tile_m = tile_ / L.ntn;
-  const int tp = blockIdx.y;
   const int m0 = tile_m * BT, n0 = tile_n * BT;
   const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
   const float* g0 = d.g.p0 + b0 * d.g_bs0 + b1 * d.g_bs1;
@@ -1458,13 +1459,14 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradLaunch L) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
-  // gridDim.x = pixel slices x tiles, slice-major behind the XCD remap: one XCD's L2 sees one contiguous range of
-  // pixels of both operands (for all tiles and, via gridDim.y, all taps) instead of every XCD streaming all of them
-  const int ntiles_ = gridDim.x / L.splitk;
-  const int wg_ = xcd_contiguous(blockIdx.x, gridDim.x);
+  // gridDim.x = (pixel slices x tiles) x taps, slice-major behind the XCD remap with the taps of a (slice, tile) as
+  // neighbours: one XCD's L2 sees one contiguous range of pixels of both operands for all tiles and all taps instead of
+  // every XCD streaming all of them (with the taps in gridDim.y they kept their XCD only when gridDim.x was a multiple of 8)
+  const int c_ = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int tp = c_ % d.ntaps, wg_ = c_ / d.ntaps;
+  const int ntiles_ = (gridDim.x / d.ntaps) / L.splitk;
   const int ks = wg_ / ntiles_, tile_ = wg_ - ks * ntiles_;
   const int tile_n = tile_ % L.ntn, tile_m = tile_ / L.ntn;
-  const int tp = blockIdx.y;
   const int m0 = tile_m * BT, n0 = tile_n * BT;
   const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
   const float* g0 = d.g.p0 + b0 * d.g_bs0 + b1 * d.g_bs1;
@@ -1596,7 +1598,7 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradLaunch L) {
 template <int BT, int WM, int WN, int NBUF>
 static int launch_wgrad_glds(const WgradLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * NBUF * BK * BT * sizeof(float);
-  dim3 grid(ntm * L.ntn * L.splitk, L.d.ntaps, L.d.batch);
+  dim3 grid(ntm * L.ntn * L.splitk * L.d.ntaps, 1, L.d.batch);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)wgrad_glds_kernel<BT, WM, WN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1627,7 +1629,7 @@ __global__ void zero_rows_kernel(float* p, long long rows, int cols, long long l
 template <int BT, int WM, int WN, bool VEC, bool AFF>
 static int launch_wgrad(const WgradLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = 4 * BK * BT * sizeof(float);
-  dim3 grid(ntm * L.ntn * L.splitk, L.d.ntaps, L.d.batch);
+  dim3 grid(ntm * L.ntn * L.splitk * L.d.ntaps, 1, L.d.batch);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<BT, WM, WN, VEC, AFF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

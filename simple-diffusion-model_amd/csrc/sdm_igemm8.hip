@@ -56,6 +56,12 @@ __device__ __forceinline__ void dsr8(f32x4& v, unsigned addr) {
 }
 #define IC8(v) std::integral_constant<int, (v)>()
 
+// TAPIN: K walk with the TAPS INNERMOST (64-channel chunk outer): the nine taps of a chunk re-read activation rows that are
+// one pixel / one image row apart, so an XCD's tiles keep the chunk's rows (~0.8 MB) in their 4 MB L2 across the taps instead of
+// re-streaming the whole 4 MB of tile rows once per tap (profiles/r04_igemm8_fwd512_pmc.json: L2-miss reads 4.8x algorithmic).
+// Per-row validity of every tap is a bit mask made in the prologue, the taps' row offsets and weight-slice indices sit in the
+// lanes of two registers (v_readlane by the uniform tap index): no table reads in the loop.
+template <bool TAPIN>
 __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
   const sdm_igemm_desc& d = L.d;
   extern __shared__ __align__(16) char smem8[];
@@ -132,10 +138,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
   const bf16_t* pA[2][2];
   int stA[2][2];
   const bf16_t* pB[2][2];
-  // K walk of a tap: K-tiles rot, rot + 1, .., kch - 1, 0, .., rot - 1 (rot = 0 unless L.krot: see BfLaunch)
-  const int rot = L.krot ? tile_id % kch : 0;
-  int tpA[2] = {0, 0}, kcA[2] = {rot, rot}, cnA[2] = {0, 0}, tpB[2] = {0, 0}, kcB[2] = {rot, rot}, cnB[2] = {0, 0};
-  const bool one_src = kch0 >= kch;
+  int tpA[2] = {0, 0}, kcA[2] = {0, 0}, tpB[2] = {0, 0}, kcB[2] = {0, 0};
   // A half h: pointers of the segment (tap tp, from K-tile kc of that tap)
   auto seg_a = [&](auto hc, int tp, int kc) {
     constexpr int h = decltype(hc)::value;
@@ -158,48 +161,76 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
     for (int i = 0; i < 2; ++i) {
       int n = n0 + h * 128 + i * 64 + srow;
       n = n < N ? n : N - 1;
-      pB[h][i] = bw + (long long)s_tap[2 * SDM_MAX_TAPS] * d.b_tap_stride + (long long)n * d.ldb + cc8 + (rot << 6);
+      pB[h][i] = bw + (long long)(TAPIN ? 0 : s_tap[2 * SDM_MAX_TAPS]) * d.b_tap_stride + (long long)n * d.ldb + cc8;
     }
-  seg_a(IC8(0), 0, rot);
-  seg_a(IC8(1), 0, rot);
+  // TAPIN state: tap tables in lanes, per-row tap validity masks, row base pointers of both concatenated sources
+  int lane_dw = 0, lane_tw = 0;
+  unsigned mskA[2][2] = {{0u, 0u}, {0u, 0u}};
+  const bf16_t* bA0[2][2];
+  const bf16_t* bA1[2][2];
+  if constexpr (TAPIN) {
+    lane_dw = lane < ntap ? s_tap[lane] * d.a.W + s_tap[SDM_MAX_TAPS + lane] : 0;
+    lane_tw = lane < ntap ? s_tap[2 * SDM_MAX_TAPS + lane] : 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        unsigned mk = 0u;
+        for (int t = 0; t < ntap; ++t) {
+          const int sy = a_y[h][i] + s_tap[t], sx = a_x[h][i] + s_tap[SDM_MAX_TAPS + t];
+          if ((unsigned)sy < (unsigned)d.a.H && (unsigned)sx < (unsigned)d.a.W) mk |= 1u << t;
+        }
+        mskA[h][i] = mk;
+        bA0[h][i] = a0 + (long long)a_row[h][i] * d.a.ld0 + cc8;
+        bA1[h][i] = a1 ? a1 + (long long)a_row[h][i] * d.a.ld1 + cc8 : zero;
+      }
+    tpA[0] = tpA[1] = tpB[0] = tpB[1] = 0;
+    kcA[0] = kcA[1] = kcB[0] = kcB[1] = 0;
+  } else {
+    seg_a(IC8(0), 0, 0);
+    seg_a(IC8(1), 0, 0);
+  }
 
   char* lds_w = smem8 + wave * 1024;
   // staging s = 4 T + j : j = 0 B half 0, 1 A half 0, 2 B half 1, 3 A half 1 ; slot = s & 7
   auto stage = [&](auto jc, auto slotc) {
     constexpr int j = decltype(jc)::value, slot = decltype(slotc)::value, h = j >> 1;
     char* dst = lds_w + slot * HT8;
+    if constexpr (TAPIN) {
+      if constexpr ((j & 1) == 0) {
+        const long long off = (long long)__builtin_amdgcn_readlane(lane_tw, tpB[h]) * d.b_tap_stride + (kcB[h] << 6);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(pB[h][0] + off), (lds_ptr)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(pB[h][1] + off), (lds_ptr)(dst + 8192), 16, 0, 0);
+        if (++tpB[h] == ntap) { tpB[h] = 0; ++kcB[h]; }
+      } else {
+        const int tp = tpA[h], kc = kcA[h];
+        const long long dw = __builtin_amdgcn_readlane(lane_dw, tp);
+        const bool second = kc >= kch0;
+        const long long off = second ? dw * d.a.ld1 + ((kc - kch0) << 6) : dw * d.a.ld0 + (kc << 6);
+        const bf16_t* q0 = ((mskA[h][0] >> tp) & 1u) ? (second ? bA1[h][0] : bA0[h][0]) + off : zero;
+        const bf16_t* q1 = ((mskA[h][1] >> tp) & 1u) ? (second ? bA1[h][1] : bA0[h][1]) + off : zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr)q0, (lds_ptr)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)q1, (lds_ptr)(dst + 8192), 16, 0, 0);
+        if (++tpA[h] == ntap) { tpA[h] = 0; ++kcA[h]; }
+      }
+    } else
     if constexpr ((j & 1) == 0) {
       __builtin_amdgcn_global_load_lds((glb_ptr)pB[h][0], (lds_ptr)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((glb_ptr)pB[h][1], (lds_ptr)(dst + 8192), 16, 0, 0);
       long long step = 64;
-      const int kc_last = kcB[h];
-      if (++cnB[h] == kch) {                               // next tap's weight slice, from its K-tile rot on
-        cnB[h] = 0;
-        kcB[h] = rot;
-        const int t = tpB[h]++;
-        step = (rot - kc_last) * 64;
-        if (t + 1 < ntap) step += (long long)(s_tap[2 * SDM_MAX_TAPS + t + 1] - s_tap[2 * SDM_MAX_TAPS + t]) * d.b_tap_stride;
-      } else if (++kcB[h] == kch) {                        // wrap inside the tap
+      if (++kcB[h] == kch) {                               // next tap's weight slice
         kcB[h] = 0;
-        step = 64 - K;
+        const int t = tpB[h]++;
+        if (t + 1 < ntap) step = (long long)(s_tap[2 * SDM_MAX_TAPS + t + 1] - s_tap[2 * SDM_MAX_TAPS + t]) * d.b_tap_stride - (K - 64);
       }
       pB[h][0] += step;
       pB[h][1] += step;
     } else {
       __builtin_amdgcn_global_load_lds((glb_ptr)pA[h][0], (lds_ptr)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((glb_ptr)pA[h][1], (lds_ptr)(dst + 8192), 16, 0, 0);
-      if (++cnA[h] == kch) {
-        cnA[h] = 0;
-        kcA[h] = rot;
-        if (++tpA[h] < ntap) seg_a(IC8(h), tpA[h], rot);
-      } else if (++kcA[h] == kch) {                        // wrap inside the tap
+      if (++kcA[h] == kch) {
         kcA[h] = 0;
-        if (one_src) {                                     // (stA is 64 for a row inside the image, 0 for the zero chunk)
-          pA[h][0] -= (kch - 1) * stA[h][0];
-          pA[h][1] -= (kch - 1) * stA[h][1];
-        } else {
-          seg_a(IC8(h), tpA[h], 0);
-        }
+        if (++tpA[h] < ntap) seg_a(IC8(h), tpA[h], 0);
       } else if (kcA[h] == kch0) {
         seg_a(IC8(h), tpA[h], kcA[h]);                     // the second concatenated source starts
       } else {
@@ -523,11 +554,13 @@ int sdm_launch_igemm8_bf16(const BfLaunch& L0, int ntm, hipStream_t st) {
   BfLaunch L = L0;
   L.kchunks = L.d.K / 64;
   static bool attr_set = false;
-  auto kern = igemm8_bf16_kernel;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)igemm8_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)igemm8_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  static const char* tapin_s = getenv("SDM_BF16_TAPIN");     // "1": taps innermost in the K walk (see the kernel)
+  const bool tapin = tapin_s && tapin_s[0] == '1';
   dim3 grid(ntm * L.ntn, L.d.nphase, L.d.batch);
   double taps = 0;
   for (int p = 0; p < L.d.nphase; ++p) taps += L.d.ntaps[p];
@@ -537,7 +570,8 @@ int sdm_launch_igemm8_bf16(const BfLaunch& L0, int ntm, hipStream_t st) {
     sdm_prof_shape(L.d.M, L.d.N, L.d.K, (int)taps, 1, 2.0 * L.d.batch * (in_b + w_b + out_b));
   }
   sdm_prof_pre(st);
-  SDM_LAUNCH(kern, grid, dim3(512), lds, st, L);
+  if (tapin) SDM_LAUNCH(igemm8_bf16_kernel<true>, grid, dim3(512), lds, st, L);
+  else SDM_LAUNCH(igemm8_bf16_kernel<false>, grid, dim3(512), lds, st, L);
   sdm_prof_post(st, 0, 2.0 * L.d.M * L.d.N * L.d.K * taps * L.d.batch);
   SDM_CHECK_LAUNCH("igemm8_bf16");
   return SDM_OK;

@@ -87,11 +87,16 @@ __global__ __launch_bounds__(512, 2) void wgrad8x3_bf16_kernel(const Wgrad3Launc
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3, h = lane >> 5;
-  const int ntiles_ = gridDim.x / L.splitk;
-  const int wg_ = xcd_contiguous_w8(blockIdx.x, gridDim.x);
+  // 1-D grid of (pixel slice x tile) x 3 kernel rows.  The three kernel rows of one (slice, tile) read the SAME gradient rows and
+  // activation rows shifted by one image row: they are made neighbours of one XCD's contiguous run (c, c + 1, c + 2), so that
+  // they run at the same time on one L2 and two of the three reads hit it (as separate grid rows they landed on different XCDs
+  // whenever the slice count was not a multiple of 8, and every kernel row streamed its operands from HBM: 3.0x algorithmic).
+  const int c_ = xcd_contiguous_w8(blockIdx.x, gridDim.x);
+  const int dyi = c_ % 3, wg_ = c_ / 3;
+  const int ntiles_ = (gridDim.x / 3) / L.splitk;
   const int ks = wg_ / ntiles_, tile_ = wg_ - ks * ntiles_;
   const int tile_n = tile_ % L.ntn, tile_m = tile_ / L.ntn;
-  const int dyi = blockIdx.y, dy = L.dy[dyi];
+  const int dy = L.dy[dyi];
   const int m0 = tile_m * 128, n0 = tile_n * 128;
   const bf16_t* g0 = (const bf16_t*)d.g.p0;
   const bf16_t* x0 = (const bf16_t*)d.x.p0;
@@ -362,7 +367,7 @@ int sdm_launch_wgrad8x3_bf16(const Wgrad3Launch& L3, hipStream_t st) {
     sdm_prof_shape(d->M, d->N, (int)P, 9, L3.splitk, 2.0 * (g_b + x_b) + 4.0 * w_b);
   }
   sdm_prof_pre(st);
-  const dim3 grid(cdiv(d->M, 128) * L3.ntn * L3.splitk, 3, 1);
+  const dim3 grid(cdiv(d->M, 128) * L3.ntn * L3.splitk * 3, 1, 1);
   static const char* dbg_s = getenv("SDM_WGRAD8_DBG");
   const int dbg = dbg_s ? atoi(dbg_s) : 0;
   if (dbg && d->Wk >= 64) {

@@ -42,6 +42,7 @@ for what in "$@"; do
     dump)    SDM_PROF_DUMP=gpurun_out/r04_train_step_launches.csv timeout -k 10 200 python bench.py --steps 5 --warmup 3 --no-configs --no-cpu-baseline > gpurun_out/prof_dump.json 2> gpurun_out/prof_dump.err; wc -l gpurun_out/r04_train_step_launches.csv ;;
     pmc_attn) bash tools/pmc_attn.sh 1 twopass > gpurun_out/r4_pmc_attn1.txt 2>&1; tail -30 gpurun_out/r4_pmc_attn1.txt ;;
     pmc_conv) conv_pmc igemm8_fwd512 igemm8_bf16_kernel "forward Conv2d 512->512 k3 on 8 images of 64x64 (M=32768, N=512, K=512 x 9 taps), bf16, phase-interleaved 256x256 tile" 154618822656 71827456 8 64 64 512 512 c3s1 4 fwd ;;
+    pmc_conv_tapin) SDM_BF16_TAPIN=1 conv_pmc igemm8_tapin_fwd512 igemm8_bf16_kernel "forward Conv2d 512->512 k3 on 8 images of 64x64 (M=32768, N=512, K=512 x 9 taps), bf16, phase-interleaved 256x256 tile, taps innermost in the K walk" 154618822656 71827456 8 64 64 512 512 c3s1 4 fwd ;;
     pmc_wgrad) conv_pmc wgrad8_512 wgrad8x3_bf16_kernel "weight gradient of Conv2d 512->512 k3 on 8 images of 64x64 (M=N=512, 32768 pixels), bf16, three taps per workgroup, phase-interleaved" 154618822656 76546048 8 64 64 512 512 c3s1 4 wgrad && conv_pmc wgrad8_128 wgrad8x3_bf16_kernel "weight gradient of Conv2d 128->128 k3 on 8 images of 256x256 (M=N=128, 524288 pixels), bf16, three taps per workgroup, phase-interleaved" 154618822656 269025280 8 256 256 128 128 c3s1 4 wgrad ;;
     *) echo "unknown $what" ;;
   esac
