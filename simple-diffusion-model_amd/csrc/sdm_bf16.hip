@@ -56,23 +56,6 @@ __device__ __forceinline__ void wait_lgkmcnt_bf() {
 // FAST: K and the concat split are multiples of the 64-element K-step, so a K-step never straddles the reduction end or
 // the two concatenated sources; the DMA addresses are then per-lane pointers advanced by one add per K-step (rows outside
 // the image point at a zero chunk with step 0) and rebuilt only when the (tap, source) segment changes.
-// ---- split-K finished inside the kernel (see sdm_igemm.hip: splitk_arrive / splitk_finish_tile): the last-arriving
-// workgroup of a tile reads the fp32 sums back from L2, applies the epilogue and leaves sums and counter zero.
-__device__ __forceinline__ bool splitk_arrive_bf(const BfLaunch& L, int phase, int* s_flag) {
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned* ctr = (unsigned*)(L.d.ws + L.ctr_off) + ((long long)(blockIdx.z * L.d.nphase + phase) * gridDim.x + blockIdx.x);
-    const unsigned prev = atomicAdd(ctr, 1u);
-    const int last = prev == (unsigned)L.splitk - 1u;
-    if (last) atomicExch(ctr, 0u);
-    *s_flag = last;
-  }
-  __syncthreads();
-  const bool last = *s_flag != 0;
-  if (last) __threadfence();
-  return last;
-}
 template <int BM, int BN, int NT>
 __device__ __forceinline__ void splitk_finish_tile_bf(const BfLaunch& L, const long long* s_orow, int n0) {
   const sdm_igemm_desc& d = L.d;
@@ -662,10 +645,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
           if (orow >= 0) atomicAdd(wsb + orow * N + col, acc[i][j][r]);
         }
       }
-    if (L.ctr_off >= 0) {
-      __shared__ int s_lastflag;
-      if (splitk_arrive_bf(L, phase, &s_lastflag)) splitk_finish_tile_bf<BM, BN, 64 * WM * WN>(L, s_orow, n0);
-    }
     return;
   }
 #pragma unroll
@@ -1086,15 +1065,6 @@ static void bf_plan(const sdm_igemm_desc* d, bool big_ok, int* cfg, int* splitk,
   *ws_need = sk > 1 ? (size_t)out_rows * d->batch * d->N * sizeof(float) : 0;
 }
 
-static size_t bf_counter_bytes(const sdm_igemm_desc* d, int cfg) {
-  const long tiles = (long)cdiv(d->M, kBfCfgs[cfg].bm) * cdiv(d->N, kBfCfgs[cfg].bn) * d->nphase * d->batch;
-  return (size_t)tiles * sizeof(unsigned);
-}
-static bool bf_splitk_inkernel() {
-  static const char* e = getenv("SDM_SPLITK_INKERNEL");     // opt-in, measured slower: see splitk_inkernel() in sdm_igemm.hip
-  return e && e[0] == '1';
-}
-
 template <int BM, int BN, int WM, int WN, int NBUF, bool FAST, bool XS = false, int KE = 64, bool PP = false>
 static int launch_bf(const BfLaunch& L0, int ntm, hipStream_t st) {
   constexpr size_t lds = (size_t)NBUF * (BM + BN) * (KE / 2) * sizeof(float) + BM * sizeof(long long) + 3 * SDM_MAX_TAPS * sizeof(int);
@@ -1175,7 +1145,6 @@ extern "C" size_t sdm_igemm_bf16_workspace_bytes(const sdm_igemm_desc* d) {
   int b, sk;
   size_t need;
   bf_plan(d, false, &b, &sk, &need);     // an upper bound: the large tiles never split K
-  if (sk > 1 && bf_splitk_inkernel()) need = ((need + 15) & ~(size_t)15) + bf_counter_bytes(d, b);
   return need;
 }
 
@@ -1247,11 +1216,6 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
   size_t need;
   bf_plan(d, fast && L.vec_epi, &cfg, &L.splitk, &need);
   if (L.splitk > 1 && (d->ws == nullptr || d->ws_bytes < need)) L.splitk = 1;
-  L.ctr_off = -1;
-  if (L.splitk > 1 && !d->defer_epilogue && bf_splitk_inkernel()) {
-    const size_t sums = (need + 15) & ~(size_t)15;
-    if (d->ws_bytes >= sums + bf_counter_bytes(d, cfg)) L.ctr_off = (long long)(sums / sizeof(float));
-  }
   if (d->col_shift && !L.vec_epi)
     return sdm_set_error(SDM_ERR_ARG, "igemm_bf16: the column shift / factor epilogue needs N %% 4 == 0 and aligned output rows");
   const int bm = kBfCfgs[cfg].bm, bn = kBfCfgs[cfg].bn;
@@ -1316,7 +1280,6 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
   else rc = sdm_set_error(SDM_ERR_ARG, "igemm_bf16: tile configuration %d needs the FAST path, the vector epilogue and no split-K", cfg);
   if (rc != SDM_OK) return rc;
   if (L.splitk > 1 && d->defer_epilogue) return SDM_DEFERRED;   // raw fp32 sums stay in ws for sdm_gn_apply_fused_bf16
-  if (L.splitk > 1 && L.ctr_off >= 0) return SDM_OK;            // finished inside the kernel by each tile's last arrival
   if (L.gn_stats) return SDM_STATS_DONE;
   if (L.splitk > 1) {
     const long out_rows = (long)(d->M / (d->Ht * d->Wt)) * d->Ho * d->Wo;

@@ -12,8 +12,6 @@ struct BfLaunch {
   int pow2, lw, lhw;    // prologue shortcuts, as in sdm_igemm.hip: Wt == 1 << lw, Ht * Wt == 1 << lhw
   int plain_out;        // output row == tile-grid row
   int pp;               // 8-wave tiles: ping-pong schedule of the two 4-wave halves (see the kernel)
-  long long ctr_off;    // split-K finished inside the kernel by each tile's last-arriving workgroup (sdm_igemm.hip): index
-                        // (in floats) of the per-tile arrival counters inside d.ws; -1: the separate finishing launch
 };
 
 // sdm_igemm8.hip: the phase-interleaved 256x256 tile (FAST addressing, vector epilogue, no split-K)

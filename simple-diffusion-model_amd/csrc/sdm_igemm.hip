@@ -27,8 +27,6 @@ struct IgemmLaunch {
   // prologue, a measurable part of the ~7 us a launch of a few K-steps takes (tools/scratch/tiny_igemm.py)
   int pow2, lw, lhw;    // Wt == 1 << lw and Ht * Wt == 1 << lhw
   int plain_out;        // output row == tile-grid row (one phase, unit output stride, Ho x Wo == Ht x Wt)
-  long long ctr_off;    // split-K finished INSIDE the kernel by each tile's last-arriving workgroup: index (in floats) of the
-                        // per-tile arrival counters inside d.ws, behind the sums; -1: the separate finishing launch
 };
 
 static inline int ilog2_exact(long v) {   // log2 of a power of two, else -1
@@ -52,54 +50,6 @@ static inline void igemm_geometry(IgemmLaunch& L) {
 __device__ __forceinline__ int xcd_contiguous(int bid, int total) {
   const int q = total >> 3, r = total & 7, x = bid & 7, i = bid >> 3;
   return x < r ? x * (q + 1) + i : r * (q + 1) + (x - r) * q + i;
-}
-
-// ---- split-K finished inside the contraction kernel ---------------------------------------------------------------
-// A split launch used to be followed by splitk_epilogue_kernel (bias, activation, residuals over the raw sums): ~60 extra
-// launches per 64x64 training step, 20 per N=1 sampling step, each ~4.6 us on the GPU and ~10 us of host enqueue.  Now every
-// tile has an arrival counter in the zero-filled scratch (behind the sums).  A workgroup adds its partial sums with
-// device-scope atomics, fences, and bumps the tile's counter; the workgroup that finds splitk - 1 earlier arrivals is the
-// LAST one -- every other slice's sums are in L2 -- and finishes the tile: reads the sums back (agent-scope loads: L2, never
-// a stale L1 line), applies the epilogue, writes the output rows, and leaves sums and counter zero for the next launch.
-// Nobody waits for anybody (no spin, nothing to bound): the finishing work simply falls to whoever arrives last.
-__device__ __forceinline__ bool splitk_arrive(const IgemmLaunch& L, int phase, int* s_flag) {
-  __threadfence();                       // this thread's atomics are ordered before the arrival below (device scope)
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned* ctr = (unsigned*)(L.d.ws + L.ctr_off) + ((long long)(blockIdx.z * L.d.nphase + phase) * gridDim.x + blockIdx.x);
-    const unsigned prev = atomicAdd(ctr, 1u);
-    const int last = prev == (unsigned)L.splitk - 1u;
-    if (last) atomicExch(ctr, 0u);       // zero-filled contract of the scratch
-    *s_flag = last;
-  }
-  __syncthreads();
-  const bool last = *s_flag != 0;
-  if (last) __threadfence();             // acquire side: the other slices' sums are visible to the loads below
-  return last;
-}
-
-template <int BM, int BN>
-__device__ __forceinline__ void splitk_finish_tile(const IgemmLaunch& L, const long long* s_orow, int n0) {
-  const sdm_igemm_desc& d = L.d;
-  const int N = d.N;
-  const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
-  const long long obo = b0 * d.o_bs0 + b1 * d.o_bs1, rbo = b0 * d.r_bs0 + b1 * d.r_bs1;
-  float* wsb = d.ws + (long long)blockIdx.z * L.out_rows * N;
-  for (int e = threadIdx.x; e < BM * BN; e += 256) {
-    const int r = e / BN, col = n0 + (e % BN);
-    const long long orow = s_orow[r];
-    if (orow < 0 || col >= N) continue;
-    float* w = wsb + orow * N + col;
-    float v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *w = 0.f;
-    v = v * d.alpha + (d.bias ? d.bias[col] : 0.f);
-    if (d.out_preact) d.out_preact[obo + orow * d.ldo + col] = v;
-    v = sdm_act(v, d.act);
-    if (d.res) v += d.res[rbo + orow * d.ldres + col];
-    if (d.res2) v += d.res2[orow * d.ldres2 + col];
-    if (d.dact_z && (d.dact_ncols == 0 || col < d.dact_ncols)) v *= sdm_dsilu(d.dact_z[orow * d.ldz + col]);
-    d.out[obo + orow * d.ldo + col] = v;
-  }
 }
 
 // One K-step = (tap, 32-channel chunk).  Per-tap state (row pointers, validity) is rebuilt only when the tap
@@ -410,10 +360,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
       }
     }
   }
-  if (L.splitk > 1 && L.ctr_off >= 0) {
-    __shared__ int s_lastflag;
-    if (splitk_arrive(L, phase, &s_lastflag)) splitk_finish_tile<BM, BN>(L, s_orow, n0);
-  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -661,10 +607,6 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
           if (orow >= 0) atomicAdd(wsb + orow * N + col, acc[i][j][r]);
         }
       }
-    if (L.ctr_off >= 0) {
-      __shared__ int s_lastflag;
-      if (splitk_arrive(L, phase, &s_lastflag)) splitk_finish_tile<BM, BN>(L, s_orow, n0);
-    }
     return;
   }
   const long long obo = b0 * d.o_bs0 + b1 * d.o_bs1;
@@ -1097,28 +1039,17 @@ static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* w
   *ws_need = bs > 1 ? (size_t)out_rows * d->batch * N * sizeof(float) : 0;
 }
 
-// arrival counters of the in-kernel split-K finish: one per (tile, phase, batch entry), behind the sums (16-byte aligned)
-static size_t splitk_counter_bytes(const sdm_igemm_desc* d, int cfg) {
-  const long tiles = (long)cdiv(d->M, kCfgs[cfg].bm) * cdiv(d->N, kCfgs[cfg].bn) * d->nphase * d->batch;
-  return (size_t)tiles * sizeof(unsigned);
-}
-static bool splitk_inkernel() {
-  // OPT-IN (SDM_SPLITK_INKERNEL=1).  Measured on MI355X (round 4, gpurun_out/r4_call11: profiles/r04_splitk_inkernel.txt):
-  // the 64x64 training step 7.35 -> 9.01 ms, the N=1 sampling step 1.10 -> 1.51 ms (fp32) / 0.78 -> 1.02 ms (bf16) although
-  // 47 / 20 / 9 launches per step are gone.  Every slice has to make its atomics visible at agent scope before it bumps
-  // the counter, and on this chip (eight XCDs, one L2 each) an agent-scope release is an L2 write-back + invalidate
-  // (buffer_wbl2 / buffer_inv) executed by EVERY workgroup at its tail; the separate finishing launch gets the same ordering
-  // for free from the kernel boundary.  Round 2 had measured the same design (with returning exchanges) at -5 %.
-  static const char* e = getenv("SDM_SPLITK_INKERNEL");
-  return e && e[0] == '1';
-}
-
+// (Split-K finished INSIDE the contraction kernel by each tile's last-arriving workgroup was built twice -- round 2 with returning
+// exchanges, round 4 with agent-scope loads and arrival counters behind the sums (commit 3bcda65) -- and measured slower both
+// times: round 4, 64x64 training step 7.35 -> 9.01 ms, N=1 sampling step 1.10 -> 1.51 ms although 47 / 20 launches per step were
+// gone (profiles/r04_splitk_inkernel.txt).  Every slice must release its atomics at agent scope before it arrives, which on
+// eight XCDs with one L2 each is an L2 write-back + invalidate per workgroup; the kernel boundary gives the separate finishing
+// launch that ordering for free.  Even switched off, the extra code cost the 64x64 class 3 % (registers): removed.)
 extern "C" size_t sdm_igemm_workspace_bytes(const sdm_igemm_desc* d) {
   if (igemm_validate(d) != SDM_OK) return 0;
   int c, sk;
   size_t need;
   igemm_plan(d, &c, &sk, &need);
-  if (sk > 1 && c != 4 && splitk_inkernel()) need = ((need + 15) & ~(size_t)15) + splitk_counter_bytes(d, c);
   return need;
 }
 
@@ -1179,11 +1110,6 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
     need = 0;
   }
   if (L.splitk > 1 && (d->ws == nullptr || d->ws_bytes < need)) L.splitk = 1;  // no scratch: run unsplit
-  L.ctr_off = -1;
-  if (L.splitk > 1 && cfg != 4 && !d->defer_epilogue && splitk_inkernel()) {
-    const size_t sums = (need + 15) & ~(size_t)15;
-    if (d->ws_bytes >= sums + splitk_counter_bytes(d, cfg)) L.ctr_off = (long long)(sums / sizeof(float));
-  }
   L.kchunks = cdiv(d->K, BK);
   const bool vecA = aligned16(d->a.p0) && d->a.ld0 % 4 == 0 && d->a_bs0 % 4 == 0 && d->a_bs1 % 4 == 0 &&
                     (d->a.p1 == nullptr || (aligned16(d->a.p1) && d->a.ld1 % 4 == 0));
@@ -1224,7 +1150,6 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
   else rc = dispatch_igemm<128, 64, 2, 2>(L, ntm, km, vec, aff, st);
   if (rc != SDM_OK) return rc;
   if (finish && d->defer_epilogue) return SDM_DEFERRED;     // raw sums stay in ws: the caller's next kernel finishes them
-  if (finish && L.ctr_off >= 0) return SDM_OK;              // finished inside the kernel by each tile's last arrival
   if (finish) {
     const long long total = (long long)out_rows * d->batch * d->N;
     int grid = (int)((total + 1023) / 1024);
@@ -1270,14 +1195,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
-  // gridDim.x = (pixel slices x tiles) x taps, slice-major behind the XCD remap with the taps of a (slice, tile) as
-  // neighbours: one XCD's L2 sees one contiguous range of pixels of both operands for all tiles and all taps instead of
-  // every XCD streaming all of them (with the taps in gridDim.y they kept their XCD only when gridDim.x was a multiple of 8)
-  const int c_ = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int tp = c_ % d.ntaps, wg_ = c_ / d.ntaps;
-  const int ntiles_ = (gridDim.x / d.ntaps) / L.splitk;
+  // gridDim.x = pixel slices x tiles, slice-major behind the XCD remap: one XCD's L2 sees one contiguous range of
+  // pixels of both operands (for all tiles and, via gridDim.y, all taps) instead of every XCD streaming all of them.
+  // (Round 4 tried the taps of a slice as neighbours of ONE XCD run, as the bf16 kernels now have them: at the fp32 training
+  // shapes, whose operands sit in L2 anyway, the 64x64 class got 2.7 % slower and the 128x128 class 1 % faster: not adopted.)
+  const int ntiles_ = gridDim.x / L.splitk;
+  const int wg_ = xcd_contiguous(blockIdx.x, gridDim.x);
   const int ks = wg_ / ntiles_, tile_ = wg_ - ks * ntiles_;
   const int tile_n = tile_ % L.ntn, tile_m = tile_ / L.ntn;
+  const int tp = blockIdx.y;
   const int m0 = tile_m * BT, n0 = tile_n * BT;
   const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
   const float* g0 = d.g.p0 + b0 * d.g_bs0 + b1 * d.g_bs1;
@@ -1459,14 +1385,15 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradLaunch L) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
-  // gridDim.x = (pixel slices x tiles) x taps, slice-major behind the XCD remap with the taps of a (slice, tile) as
-  // neighbours: one XCD's L2 sees one contiguous range of pixels of both operands for all tiles and all taps instead of
-  // every XCD streaming all of them (with the taps in gridDim.y they kept their XCD only when gridDim.x was a multiple of 8)
-  const int c_ = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int tp = c_ % d.ntaps, wg_ = c_ / d.ntaps;
-  const int ntiles_ = (gridDim.x / d.ntaps) / L.splitk;
+  // gridDim.x = pixel slices x tiles, slice-major behind the XCD remap: one XCD's L2 sees one contiguous range of
+  // pixels of both operands (for all tiles and, via gridDim.y, all taps) instead of every XCD streaming all of them.
+  // (Round 4 tried the taps of a slice as neighbours of ONE XCD run, as the bf16 kernels now have them: at the fp32 training
+  // shapes, whose operands sit in L2 anyway, the 64x64 class got 2.7 % slower and the 128x128 class 1 % faster: not adopted.)
+  const int ntiles_ = gridDim.x / L.splitk;
+  const int wg_ = xcd_contiguous(blockIdx.x, gridDim.x);
   const int ks = wg_ / ntiles_, tile_ = wg_ - ks * ntiles_;
   const int tile_n = tile_ % L.ntn, tile_m = tile_ / L.ntn;
+  const int tp = blockIdx.y;
   const int m0 = tile_m * BT, n0 = tile_n * BT;
   const int b0 = blockIdx.z / d.bdiv, b1 = blockIdx.z % d.bdiv;
   const float* g0 = d.g.p0 + b0 * d.g_bs0 + b1 * d.g_bs1;
@@ -1598,7 +1525,7 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradLaunch L) {
 template <int BT, int WM, int WN, int NBUF>
 static int launch_wgrad_glds(const WgradLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * NBUF * BK * BT * sizeof(float);
-  dim3 grid(ntm * L.ntn * L.splitk * L.d.ntaps, 1, L.d.batch);
+  dim3 grid(ntm * L.ntn * L.splitk, L.d.ntaps, L.d.batch);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)wgrad_glds_kernel<BT, WM, WN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1629,7 +1556,7 @@ __global__ void zero_rows_kernel(float* p, long long rows, int cols, long long l
 template <int BT, int WM, int WN, bool VEC, bool AFF>
 static int launch_wgrad(const WgradLaunch& L, int ntm, hipStream_t st) {
   constexpr size_t lds = 4 * BK * BT * sizeof(float);
-  dim3 grid(ntm * L.ntn * L.splitk * L.d.ntaps, 1, L.d.batch);
+  dim3 grid(ntm * L.ntn * L.splitk, L.d.ntaps, L.d.batch);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<BT, WM, WN, VEC, AFF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1374,56 +1374,3 @@ def test_sampler_requires_labels_for_a_conditional_net(dev, O):
     c = S.ddpm_sampling(net, sch, xT, 1, 6, None, lab, "cuda", quiet)
     assert torch.allclose(a, b, rtol=1e-4, atol=1e-5) and not torch.allclose(a, c, rtol=1e-2, atol=1e-3)    # (split-K atomics: not bitwise)
     assert torch.equal(cpu_state, torch.get_rng_state())             # the key comes from the DEVICE generator
-
-
-SPLIT_CASES = [("c3s1", 1, 512, 512, 8, 8), ("c3s1", 4, 256, 384, 8, 8), ("c3s2", 2, 256, 256, 16, 16), ("ct4", 1, 512, 256, 8, 8)]
-
-
-@pytest.mark.parametrize("bf16", [False, True])
-@pytest.mark.parametrize("kind,n,cin,cout,h,w", SPLIT_CASES)
-def test_split_k_finished_inside_the_contraction_kernel_case(dev, L, bf16, kind, n, cin, cout, h, w):
-    """Body of test_split_k_finished_inside_the_contraction_kernel (runs in its subprocess with SDM_SPLITK_INKERNEL=1; in the
-    ordinary run the switch is off and the case only checks the result and the zero-filled scratch)."""
-    from sdm_hip import lib, ops
-    inkernel = os.environ.get("SDM_SPLITK_INKERNEL") == "1"
-    g = torch.Generator().manual_seed(17)
-    conv = L.TapConv(cin, cout, kind)
-    with torch.no_grad():
-        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / (cin * 9) ** 0.5)
-        conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
-    x = torch.randn(n, cin, h, w, generator=g)
-    if bf16:
-        x = x.to(torch.bfloat16).float()
-        with torch.no_grad():
-            conv.weight.copy_(conv.weight.to(torch.bfloat16).float())
-    z = torch_conv(x, conv.weight.detach().contiguous(), conv.bias.detach(), kind)
-    y = z * torch.sigmoid(z)
-    conv = conv.to(dev)
-    ctx = L.RunCtx(False, bf16=bf16)
-    a = ops.Act(rows(x).to(torch.bfloat16) if bf16 else rows(x), n, h, w)
-    wt = conv.taps_for(ctx)
-    ops.conv_fwd(a, wt, conv.bias, kind, ops.ACT_SILU)             # sizes the scratch
-    torch.cuda.synchronize()
-    for rep in range(3):
-        l0 = lib.launch_count()
-        out = ops.conv_fwd(a, wt, conv.bias, kind, ops.ACT_SILU)
-        launches = lib.launch_count() - l0
-        torch.cuda.synchronize()
-        assert launches == (1 if inkernel else 2), launches        # the cases take a split-K plan: contraction (+ finishing pass)
-        assert rel(unrows(out.t.float(), n, out.h, out.w), y) < (4e-3 if bf16 else 2e-5)
-        assert ops._all_zero(ops.WS)
-
-
-def test_split_k_finished_inside_the_contraction_kernel():
-    """OPT-IN form of split-K (SDM_SPLITK_INKERNEL=1; measured slower on MI355X, see splitk_inkernel() in csrc/sdm_igemm.hip):
-    the last-arriving workgroup of a tile reads the raw sums back, applies bias / activation / residual, and leaves sums and
-    arrival counter zero -- ONE launch per conv, the zero-filled scratch contract intact, results as before, repeatably.  The
-    switch is read once per process -> subprocess; also the golden forward and a training step of a narrow net under it."""
-    import subprocess
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
-    env = dict(os.environ, SDM_SPLITK_INKERNEL="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
-                        "split_k_finished_inside_the_contraction_kernel_case or unet_forward_golden or unet_grads_golden or conv_fwd_dgrad_wgrad"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:]
