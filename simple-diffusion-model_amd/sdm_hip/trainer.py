@@ -293,6 +293,8 @@ class DiffusionTrainer:
                 m.copy_(bm)
                 v.copy_(bv)
             del backup
+            if self.adopt_bf16 and self.opt.adopted:
+                self.opt.adopt_bf16_copies()       # the copies followed the warm-up step: bring them back to the restored weights
             self.graph = torch.cuda.CUDAGraph()
             with ops.capture_scope() as kept, torch.cuda.graph(self.graph):
                 self.g_loss = self._body(*self.g_in, hyper=self.hyper)

@@ -439,3 +439,37 @@ def test_adam_writes_the_bf16_weight_copies(dev, O):
     fresh = conv.taps_for(CL.RunCtx(True, bf16=True))
     assert torch.equal(fresh.view(torch.int16), ops.to_bf16(conv.taps()).view(torch.int16))
     assert len(conv.__dict__["_bf16_cache"]["taps"]) == 2
+
+
+def test_bf16_training_step_hipgraph_replay_matches_eager(dev, O):
+    """bf16 training through the opt-in captured step (use_graph=True) against eager stepping: the warm-up run of the capture is
+    undone on the weights, so the bf16 weight copies the fused Adam maintains must be brought back to the restored masters
+    before the capture -- three replayed steps land on the eager trainer's losses and weights."""
+    import degraders as D
+    from models.U_Net import U_Net
+    from sdm_hip.trainer import DiffusionTrainer
+    cfg = O.full_cfg(dict(num_resnet_blocks=1, in_channel=3, out_channel=3, time_dim=32, cond_dim=3, num_layers=2,
+                          attn_layers=[1], num_heads=2, dim_per_head=16, min_channel=32, max_channel=64))
+    P = O.seeded_params(cfg, seed=3, gain=1.8)
+    sched = D.CosineNoiseDegradation(1000)
+    g = torch.Generator().manual_seed(4)
+    data = [(torch.randn(4, 3, 16, 16, generator=g).cuda(), torch.eye(3)[torch.randint(0, 3, (4,), generator=g)].cuda(),
+             torch.randn(4, 3, 16, 16, generator=g).cuda(), torch.randint(1, 1000, (4,), generator=g).cuda()) for _ in range(4)]
+    out = []
+    for graph in (False, True):
+        net = U_Net(**cfg)
+        net.load_state_dict(P, strict=True)
+        net = net.cuda()
+        tr = DiffusionTrainer(net, sched, lr=1e-3, train_dtype=BF, use_graph=graph)
+        losses = [float(tr.step(x0, lab, eps=eps, t=t)) for x0, lab, eps, t in data]
+        torch.cuda.synchronize()
+        assert (tr.graph is not None) == graph
+        out.append((losses, {k: v.detach().clone() for k, v in net.state_dict().items()}))
+    (l0, s0), (l1, s1) = out
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
+    far = tot = 0
+    for k, v in s0.items():
+        if v.dtype.is_floating_point:
+            far += int(((v - s1[k]).abs() > 0.5e-3).sum())
+            tot += v.numel()
+    assert far / tot < 0.01, (far, tot)
