@@ -500,6 +500,12 @@ int sdm_stem_conv_bf16(const float* x_nchw, const float* w_tap, const float* bia
                        int images, int Cin, int H, int W, int Cout, int act, sdm_stream_t s);
 int sdm_head_conv_bf16(const uint16_t* x_nhwc, const float* w_tap, const float* bias, float* out_nchw,
                        int images, int Cin, int H, int W, int Cout, int act, sdm_stream_t s);
+/* The head conv on the matrix cores (csrc/sdm_edge_bf16.hip): bf16 rows x_nhwc (row pitch ldx elements, 16-byte aligned, the
+ * first Cin channels used; Cin = 64 or 128, otherwise SDM_ERR_UNSUPPORTED) and bf16 taps w16_tap [9][Cout][Cin] (Cout <= 16),
+ * fp32 bias, fp32 NCHW result with the activation applied.  Replaces nn.Conv2d(min_channel, out_channel, 3, 1, 1) (+ nn.Tanh)
+ * at the end of U_Net.out_layers (reference models/U_Net.py:121-130). */
+int sdm_head_conv_mfma_bf16(const uint16_t* x_nhwc, long long ldx, const uint16_t* w16_tap, const float* bias, float* out_nchw,
+                            int images, int Cin, int H, int W, int Cout, int act, sdm_stream_t s);
 /* sdm_gn_apply_fused on bf16 rows: src = the conv's finished bf16 rows (src_raw 0, pitch ld_src in elements) or the fp32
  * raw split-K sums left by sdm_igemm_bf16(defer_epilogue = 1) (src_raw 1; rounded to bf16 after bias / activation, as the
  * unfused path does, and cleared); x0 / x1 / out bf16. */

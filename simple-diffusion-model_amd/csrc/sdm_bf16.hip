@@ -1372,6 +1372,15 @@ extern "C" int sdm_stem_conv_bf16(const float* x, const float* w, const float* b
   SDM_CHECK_ARG(x && w && out && images > 0 && H > 0 && W > 0 && Cout > 0, "stem_conv_bf16: bad args");
   SDM_CHECK_ARG(Cin >= 1 && Cin <= 8, "stem_conv_bf16: Cin %d not in [1,8]", Cin);
   const long long P = (long long)images * H * W;
+  // matrix-core form (sdm_edge_bf16.hip) whenever the shape qualifies; SDM_STEM_MFMA=0 keeps the one-channel-per-thread kernel
+  static const char* mf = getenv("SDM_STEM_MFMA");
+  if (!(mf && mf[0] == '0')) {
+    const int rc = sdm_launch_stem_mfma_bf16(x, w, bias, out, out_preact, images, Cin, H, W, Cout, act, (hipStream_t)s);
+    if (rc == SDM_OK) {
+      SDM_CHECK_LAUNCH("stem_conv_mfma_bf16");
+      return SDM_OK;
+    }
+  }
   const dim3 grid(cdiv(P, STEM_PIX_BF));
 #define STEM_BF(C) SDM_LAUNCH(stem_conv_bf16_kernel<C>, grid, dim3(256), 0, (hipStream_t)s, x, w, bias, out, out_preact, images, H, W, Cout, act)
   switch (Cin) {

@@ -26,3 +26,8 @@ struct Wgrad3Launch {
   int tapw[3][3];      // weight tap index of (dy index, dx = -1, 0, +1)
 };
 int sdm_launch_wgrad8x3_bf16(const Wgrad3Launch& L3, hipStream_t st);
+
+// sdm_edge_bf16.hip: the stem conv on v_mfma_f32_16x16x4_f32 (SDM_ERR_UNSUPPORTED when the shape does not qualify: the caller
+// falls back to stem_conv_bf16_kernel)
+int sdm_launch_stem_mfma_bf16(const float* x, const float* w, const float* bias, bf16_t* out, bf16_t* preact, int images, int Cin,
+                              int H, int W, int Cout, int act, hipStream_t st);

@@ -154,6 +154,7 @@ _PROTOS = {
     "sdm_cast_bf16": (_i, [fp, fp, _sz, fp]),
     "sdm_stem_conv_bf16": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
     "sdm_head_conv_bf16": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
+    "sdm_head_conv_mfma_bf16": (_i, [fp, C.c_int64, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
     "sdm_gn_affine_bf16": (_i, [fp, _i64, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, fp, fp, fp, fp]),
     "sdm_affine_residual_bf16": (_i, [fp, _i64, fp, fp, _i, fp, _i64, fp, _i64, _i, fp, _i64, _i, _i, _i, fp]),
     "sdm_col_softmax_bf16": (_i, [fp, fp, _i, _i, _i64, _i64, fp]),

@@ -897,6 +897,7 @@ def stem_conv(x_nchw, wt, bias, act=ACT_SILU, save_z=False, out_dtype=torch.floa
 
 
 HEAD_MFMA = [True]      # bf16 rows: head conv on the matrix cores (False: the one-wave-per-pixel kernel)
+HEAD_STRIP = [os.environ.get("SDM_HEAD_STRIP", "1") != "0"]   # ... by the dedicated strip kernel (False: a tile of sdm_igemm_bf16)
 
 
 def head_conv(x, wt, bias, act=ACT_NONE, wt16=None):
@@ -905,6 +906,12 @@ def head_conv(x, wt, bias, act=ACT_NONE, wt16=None):
     FLOP, 3x faster than one wave per pixel at 128x128 / 256x256), then one pass lays the rows out as NCHW."""
     cout = wt.shape[1]
     out = torch.empty((x.n, cout, x.h, x.w), dtype=torch.float32, device=wt.device)
+    if (x.t.dtype == BF16 and wt16 is not None and HEAD_MFMA[0] and HEAD_STRIP[0] and x.t2 is None and x.scale is None
+            and x.c in (64, 128) and cout <= 16 and x.t.stride(0) % 8 == 0 and x.t.data_ptr() % 16 == 0):
+        # the strip-walking matrix-core kernel (csrc/sdm_edge_bf16.hip): rows read once, NCHW written from the accumulators
+        lib.call("sdm_head_conv_mfma_bf16", _p(x.t), x.t.stride(0), _p(wt16), _p(bias), _p(out), x.n, x.c, x.h, x.w, cout, act,
+                 _stream())
+        return out
     if x.t.dtype == BF16 and wt16 is not None and HEAD_MFMA[0] and x.c % 8 == 0:
         rows = torch.empty((x.rows, 4 * ((cout + 3) // 4)), dtype=torch.float32, device=wt.device)
         d = _base_desc(x.rows, cout, x.c)

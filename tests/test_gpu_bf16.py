@@ -404,3 +404,75 @@ def test_two_pass_column_softmax_attention(dev, n, S, heads, dk):
     r1, P1 = ops.attention_core_fwd_bf16(big, n, S, heads, dk, keep_p=True)
     assert bool(torch.isfinite(r1.float()).all()) and bool(torch.isfinite(P1.float()).all())
     assert float((P1[:, :, :S].float().sum(1) - 1).abs().max()) < 2e-2
+
+
+HEAD_CASES = [
+    # n, cin, cout, h, w, act
+    (2, 128, 3, 19, 37, "none"),      # ragged strips (37 = 2 x 14 + 9), one short segment
+    (1, 64, 1, 8, 8, "tanh"),         # one strip, 64 channels
+    (3, 128, 4, 64, 64, "none"),      # the benchmark geometry (5 strips of 14)
+    (1, 128, 16, 33, 15, "tanh"),     # full 16 output rows of the matrix tile, 33 = 4 segments of 8 + 1
+    (2, 64, 3, 1, 70, "none"),        # a one-row image
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,act", HEAD_CASES)
+def test_head_conv_strip_kernel(dev, n, cin, cout, h, w, act):
+    """sdm_head_conv_mfma_bf16 (csrc/sdm_edge_bf16.hip) vs torch's fp32 conv on the SAME bf16-rounded rows and weights: only
+    the fp32 summation order differs (the result itself is fp32), gate 2e-5; the sdm_igemm_bf16 route it replaces must agree."""
+    import torch.nn.functional as F
+    from models import custom_layers as L
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(hash((n, cin, cout, h, w)) % 2**31)
+    conv = L.TapConv(cin, cout, "c3s1")
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / (cin * 9) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+    x = torch.randn(n, cin, h, w, generator=g)
+    ref = F.conv2d(rnd(x).double(), rnd(conv.weight.detach()).double(), conv.bias.detach().double(), padding=1)
+    a = ops.ACT_NONE
+    if act == "tanh":
+        ref, a = torch.tanh(ref), ops.ACT_TANH
+    conv = conv.to(dev)
+    xr = x.permute(0, 2, 3, 1).reshape(n * h * w, cin).contiguous().to(dev).to(BF)
+    ctx = L.RunCtx(False, bf16=True)
+    assert ops.HEAD_STRIP[0]
+    w16 = conv.taps_for(ctx)                                            # (the bf16 copy of the taps is made here)
+    launches = ops.lib.raw("sdm_launch_count")()
+    got = ops.head_conv(ops.Act(xr, n, h, w), conv.taps(), conv.bias, a, wt16=w16)
+    assert ops.lib.raw("sdm_launch_count")() - launches == 1          # one kernel: no separate layout pass
+    assert got.shape == (n, cout, h, w) and got.dtype == torch.float32
+    assert rel(got, ref) < 2e-5, rel(got, ref)
+    ops.HEAD_STRIP[0] = False
+    try:
+        old = ops.head_conv(ops.Act(xr, n, h, w), conv.taps(), conv.bias, a, wt16=conv.taps_for(ctx))
+    finally:
+        ops.HEAD_STRIP[0] = True
+    assert rel(got, old) < 2e-5
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 3, 128, 19, 37), (1, 1, 32, 8, 8), (3, 3, 64, 32, 32), (1, 4, 256, 5, 7),
+                                            (1, 2, 96, 16, 16)])
+def test_stem_conv_matrix_core_kernel(dev, n, cin, cout, h, w, monkeypatch):
+    """sdm_stem_conv_bf16's fp32 matrix-core form vs torch's conv: same fp32 operands, bf16 output rounding (1 ulp = 2^-8
+    relative on an element whose fp32 value sits on a rounding boundary; rel-L2 gate 4e-3 as for every bf16 kernel)."""
+    import torch.nn.functional as F
+    from models import custom_layers as L
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(hash((n, cin, cout, h, w)) % 2**31)
+    conv = L.TapConv(cin, cout, "c3s1")
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / (cin * 9) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+    x = torch.randn(n, cin, h, w, generator=g)
+    z = F.conv2d(x.double(), conv.weight.detach().double(), conv.bias.detach().double(), padding=1)
+    ref = z * torch.sigmoid(z)
+    conv = conv.to(dev)
+    out = ops.stem_conv(x.to(dev), conv.taps(), conv.bias, ops.ACT_SILU, save_z=True, out_dtype=BF)
+    got = out.t.float().reshape(n, h, w, cout).permute(0, 3, 1, 2)
+    gz = out.z.float().reshape(n, h, w, cout).permute(0, 3, 1, 2)
+    assert rel(got, ref) < 4e-3 and rel(gz, z) < 4e-3, (rel(got, ref), rel(gz, z))
+    # element-wise: never more than one bf16 ulp away from the exactly rounded pre-activation
+    torch.cuda.synchronize()
+    zc = z.float().to(BF).float()
+    assert float(((gz.cpu() - zc).abs() / (zc.abs() + 1e-3)).max()) < 2.0 ** -7
