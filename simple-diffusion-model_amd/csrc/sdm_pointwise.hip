@@ -276,8 +276,21 @@ extern "C" int sdm_head_conv_dgrad(const float* dy, const float* w, float* dx, c
                                    int W, int Cout, sdm_stream_t s) {
   return head_conv_dgrad_impl<float>(dy, w, dx, z, images, Cin, H, W, Cout, s);
 }
+// sdm_edge_bf16.hip: the transposed conv on v_mfma_f32_16x16x4_f32 (act 3 = data-gradient mode)
+int sdm_launch_stem_mfma_bf16(const float* x, const float* w, const float* bias, bf16_t* out, bf16_t* preact, int images, int Cin,
+                              int H, int W, int Cout, int act, hipStream_t st);
 extern "C" int sdm_head_conv_dgrad_bf16(const float* dy, const float* w, uint16_t* dx, const uint16_t* z, int images, int Cin,
                                         int H, int W, int Cout, sdm_stream_t s) {
+  SDM_CHECK_ARG(dy && w && dx && images > 0 && H > 0 && W > 0, "head_conv_dgrad_bf16: bad args");
+  static const char* mf = getenv("SDM_STEM_MFMA");          // "0": the one-wave-per-pixel kernel
+  if (!(mf && mf[0] == '0') && Cout >= 1 && Cout <= 8) {
+    // (the matrix-core kernel's "input" is the gradient image with Cout planes, its "output" the Cin-channel rows)
+    const int rc = sdm_launch_stem_mfma_bf16(dy, w, nullptr, dx, const_cast<uint16_t*>(z), images, Cout, H, W, Cin, 3, (hipStream_t)s);
+    if (rc == SDM_OK) {
+      SDM_CHECK_LAUNCH("head_conv_dgrad_mfma_bf16");
+      return SDM_OK;
+    }
+  }
   return head_conv_dgrad_impl<bf16_t>(dy, w, dx, z, images, Cin, H, W, Cout, s);
 }
 

@@ -452,7 +452,7 @@ def test_head_conv_strip_kernel(dev, n, cin, cout, h, w, act):
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 3, 128, 19, 37), (1, 1, 32, 8, 8), (3, 3, 64, 32, 32), (1, 4, 256, 5, 7),
-                                            (1, 2, 96, 16, 16)])
+                                            (1, 2, 96, 16, 16), (2, 6, 128, 24, 24), (1, 8, 64, 9, 11)])
 def test_stem_conv_matrix_core_kernel(dev, n, cin, cout, h, w, monkeypatch):
     """sdm_stem_conv_bf16's fp32 matrix-core form vs torch's conv: same fp32 operands, bf16 output rounding (1 ulp = 2^-8
     relative on an element whose fp32 value sits on a rounding boundary; rel-L2 gate 4e-3 as for every bf16 kernel)."""
@@ -476,3 +476,34 @@ def test_stem_conv_matrix_core_kernel(dev, n, cin, cout, h, w, monkeypatch):
     torch.cuda.synchronize()
     zc = z.float().to(BF).float()
     assert float(((gz.cpu() - zc).abs() / (zc.abs() + 1e-3)).max()) < 2.0 ** -7
+
+
+@pytest.mark.parametrize("n,c,cout,h,w,with_z", [(2, 128, 3, 19, 37, True), (1, 64, 1, 8, 8, False), (2, 256, 4, 16, 16, True),
+                                                 (1, 96, 3, 7, 5, True)])
+def test_head_conv_data_gradient_matrix_core_kernel(dev, n, c, cout, h, w, with_z):
+    """sdm_head_conv_dgrad_bf16 (data-gradient mode of the stem kernel in csrc/sdm_edge_bf16.hip) vs torch's transposed conv
+    in float64 on the same fp32 gradient image and fp32 taps, times silu'(z) of the bf16 pre-activation: only the output is
+    rounded to bf16 (rel-L2 gate 4e-3, element-wise within one bf16 ulp of the rounded exact value)."""
+    import torch.nn.functional as F
+    from models import custom_layers as L
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(hash((n, c, cout, h, w)) % 2**31)
+    conv = L.TapConv(c, cout, "c3s1")
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / (cout * 9) ** 0.5)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    z = torch.randn(n, c, h, w, generator=g).to(BF)
+    ref = F.conv_transpose2d(dy.double(), conv.weight.detach().double(), padding=1)
+    if with_z:
+        zd = z.double()
+        sg = torch.sigmoid(zd)
+        ref = ref * (sg * (1 + zd * (1 - sg)))
+    conv = conv.to(dev)
+    zr = z.permute(0, 2, 3, 1).reshape(n * h * w, c).contiguous().to(dev)
+    dx = torch.empty((n * h * w, c), dtype=BF, device=dev)
+    ops.lib.call("sdm_head_conv_dgrad_bf16", dy.to(dev).data_ptr(), conv.taps().data_ptr(), dx.data_ptr(),
+                 zr.data_ptr() if with_z else None, n, c, h, w, cout, ops._stream())
+    got = dx.float().reshape(n, h, w, c).permute(0, 3, 1, 2)
+    assert rel(got, ref) < 4e-3, rel(got, ref)
+    rc = ref.float().to(BF).float()
+    assert float(((got.cpu() - rc).abs() / (rc.abs() + 1e-3)).max()) < 2.0 ** -6     # (sigmoid by v_rcp: 1 ulp of fp32 in the factor)
