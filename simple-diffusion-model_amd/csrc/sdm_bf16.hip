@@ -1242,7 +1242,13 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
     RowLaunch R;
     if (row_tile(d, out_f32, L.vec_epi, &R)) {      // 3x3 stride-1 geometry: one activation patch per kernel row
       const int gs = d->gn_sums != nullptr && d->N % 4 == 0;      // a tile lies inside one image by construction
-      rc = launch_row<128, 128, 2, 2>(d, R, gs, st);
+      // 128 output channels at >= 2 rounds of 256-pixel tiles: an 8-wave 256x128 tile (one weight slice per 256 pixels: 1.6x less
+      // L2 -> LDS traffic per flop than two 128x128 workgroups) exists behind SDM_BF16_ROW256=1 and is SLOWER (750 vs 772
+      // TFLOP/s at 128 x 128x128, 761 vs 772 at 32 x 256x256, profiles/r04_row256_ab.txt): the row kernel is paced by its
+      // one-barrier-per-K-step schedule, not by the feed.  Parity-tested (tests: row_patch ... forced), off by default.
+      static const char* r256 = getenv("SDM_BF16_ROW256");
+      const bool tall = d->N <= 128 && ((long)d->a.H * d->a.W) % 256 == 0 && d->M / 256 >= 512 && r256 && r256[0] == '1';
+      rc = tall ? launch_row<256, 128, 4, 2>(d, R, gs, st) : launch_row<128, 128, 2, 2>(d, R, gs, st);
       if (rc != SDM_OK) return rc;
       return gs ? SDM_STATS_DONE : SDM_OK;
     }

@@ -63,6 +63,8 @@ CONV_CASES = [
     ("c3s1", 8, 64, 128, 32, 32),       # 128x128-tile path (M = 8192)
     ("c3s1", 16, 64, 256, 64, 64),      # 256x256-tile path (M = 65536, N = 256: one full round of 256 tiles)
     ("c3s1", 12, 64, 128, 64, 64),      # row-patch kernel as planned (384 tiles of 128x128, 3x3 stride-1)
+    ("c3s1", 32, 64, 128, 64, 64),      # ... its opt-in 8-wave 256x128 tile when forced (512 tiles of 256 pixels)
+    ("c3s1", 10, 64, 96, 128, 128),     # ... with a ragged N (96 of 128 columns) and two image rows per tile
     ("c3s1", 1, 128, 72, 8, 16),        # ... its edge cases when forced (test below): one tile = a whole 8x16 image,
     ("c3s1", 2, 64, 128, 2, 64),        # a tile = two image rows, ragged N
     ("c3s1", 1, 192, 128, 1, 128),      # a one-row image
@@ -296,7 +298,7 @@ def test_residual_block_fused_tail_bf16(dev, n, c, h, w):
     assert ops._all_zero(ops.WS)
 
 
-@pytest.mark.parametrize("n,c,h,w,expect", [(10, 128, 64, 64, True), (24, 256, 32, 32, True), (16, 256, 64, 64, True), (2, 128, 16, 16, None),
+@pytest.mark.parametrize("n,c,h,w,expect", [(10, 128, 64, 64, True), (33, 128, 64, 64, True), (24, 256, 32, 32, True), (16, 256, 64, 64, True), (2, 128, 16, 16, None),
                                             (3, 64, 8, 16, None), (1, 128, 12, 12, False)])
 def test_groupnorm_statistics_from_the_conv_epilogue(dev, n, c, h, w, expect):
     """sdm_igemm_bf16 with gn_sums: per-(image, channel) sum / sum of squares of the stored outputs from the conv's epilogue
@@ -361,7 +363,7 @@ def test_row_patch_kernel_forced():
     import sys
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    env = dict(os.environ, SDM_BF16_ROW="1")
+    env = dict(os.environ, SDM_BF16_ROW="1", SDM_BF16_ROW256="1")     # (and the opt-in 256x128 tile where it is eligible)
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_bf16.py"),
                         os.path.join(here, "test_gpu_bf16_train.py"), "-q", "-x", "-k",
