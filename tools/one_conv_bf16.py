@@ -37,6 +37,26 @@ def once():
 for _ in range(2):
     once()
 torch.cuda.synchronize()
+if os.environ.get("ONE_CONV_COLD") == "1":
+    # every call behind 1 GiB of unrelated writes: weights and activations come from HBM, not from L2 / the Infinity Cache
+    junk = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    # ONE_CONV_TLB=<GiB>: additionally touch one word per 4 KiB page of a buffer that large (address-translation caches cold too)
+    tlb_gib = int(os.environ.get("ONE_CONV_TLB", "0"))
+    pages = torch.empty(tlb_gib << 28, dtype=torch.float32, device="cuda") if tlb_gib else None
+    tot = 0.0
+    for i in range(reps):
+        junk.fill_(float(i))
+        if pages is not None:
+            pages[::1024].fill_(float(i))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        once()
+        b.record()
+        torch.cuda.synchronize()
+        tot += a.elapsed_time(b)
+    us = tot / reps * 1e3
+    print(f"{mode} {kind} n{n} {h}x{w} {cin}->{cout} COLD: {us:.1f} us per call (event pair around each), {flops / us / 1e6:.0f} TFLOP/s")
+    sys.exit(0)
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
 for _ in range(reps):
