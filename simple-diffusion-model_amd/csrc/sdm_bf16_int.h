@@ -12,6 +12,7 @@ struct BfLaunch {
   int pow2, lw, lhw;    // prologue shortcuts, as in sdm_igemm.hip: Wt == 1 << lw, Ht * Wt == 1 << lhw
   int plain_out;        // output row == tile-grid row
   int pp;               // 8-wave tiles: ping-pong schedule of the two 4-wave halves (see the kernel)
+  int no_simple_epi;    // igemm8: SDM_IGEMM8_SIMPLE_EPI=0 keeps the general epilogue loop for every launch (A/B)
 };
 
 // sdm_igemm8.hip: the phase-interleaved 256x256 tile (FAST addressing, vector epilogue, no split-K)

@@ -43,6 +43,24 @@
 
 __device__ float g_zero_chunk_8[4];
 
+// -DSDM_IGEMM8_TIMING (tools/igemm8_timing.sh builds a second library with it; never in the product build): wave 0 of every
+// workgroup stamps s_memrealtime (100 MHz) at entry, after the prologue tables, when the first operands have arrived, after the
+// K loop and after the epilogue; sdm_debug_igemm8_times copies the table out.
+#ifdef SDM_IGEMM8_TIMING
+#define T8_MAXWG 16384
+__device__ unsigned long long g_t8[T8_MAXWG][6];
+#define T8_STAMP(i)                                                                                              \
+  do {                                                                                                           \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < T8_MAXWG) g_t8[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+extern "C" int sdm_debug_igemm8_times(unsigned long long* host, int nwg) {
+  if (nwg > T8_MAXWG) nwg = T8_MAXWG;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_t8), (size_t)nwg * 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#else
+#define T8_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ int xcd_contiguous_8(int bid, int total) {   // see sdm_igemm.hip
   const int q = total >> 3, r = total & 7, x = bid & 7, i = bid >> 3;
   return x < r ? x * (q + 1) + i : r * (q + 1) + (x - r) * q + i;
@@ -65,6 +83,7 @@ template <bool TAPIN>
 __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
   const sdm_igemm_desc& d = L.d;
   extern __shared__ __align__(16) char smem8[];
+  T8_STAMP(0);
   long long* s_orow = (long long*)(smem8 + RING8);
   int* s_tap = (int*)(s_orow + 256);
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -318,8 +337,10 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
   if (4 < S) { stage(IC8(0), IC8(4)); ++issued; }
   if (5 < S) { stage(IC8(1), IC8(5)); ++issued; }
   if (6 < S) { stage(IC8(2), IC8(6)); ++issued; }
+  T8_STAMP(1);
   wait_younger(issued - 2);
   __builtin_amdgcn_s_barrier();
+  T8_STAMP(2);
   read_b(IC8(0), fx);
   if (wr == 1) __builtin_amdgcn_s_barrier();
 
@@ -358,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
     }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();     // every wave has passed the same number of barriers; the ring is free
+  T8_STAMP(3);
 
   // ---- epilogue.  acc[qa][qb][r][c][e] is output (tile row qa*128 + wr*64 + r*16 + l15, tile column qb*128 + wc*32 + c*16
   // + lq*4 + e): four consecutive columns of one row per lane.
@@ -451,6 +473,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
   const f32x4 cmul4 = (d.col_mul && col_ok) ? *(const f32x4*)(d.col_mul + (long long)blockIdx.z * d.colvec_bs + mycol) : one4;
   f32x4 gs = zero4, gq = zero4;                // GroupNorm statistics of this thread's 4 columns (over its rows)
   char* Ct = smem8;
+  const bool simple = !d.col_shift && !res16 && !res216 && !dz16 && !L.out_f32 && L.plain_out && d.alpha == 1.0f &&
+                      (d.act == SDM_ACT_NONE || d.act == SDM_ACT_SILU) && !L.no_simple_epi;
 #pragma unroll
   for (int qa = 0; qa < 2; ++qa) {
     if (qa) __syncthreads();                   // slab 0 has been read
@@ -465,6 +489,57 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
           *(f32x4*)(Ct + row * 1024 + ((quad ^ l15) << 4)) = acc[qa][qb][r][c];
         }
     __syncthreads();
+    if (simple) {
+      // the forward conv's epilogue (bias, SiLU or nothing, bf16 rows in tile order, optional pre-activation copy and
+      // GroupNorm sums) as a straight loop: output pointers advance by 8 rows per trip, no table lookups, no per-option
+      // address arithmetic -- the general loop below is ~200 instructions per trip and took 17-22 us per tile
+      // (profiles/r04_igemm8_timing.txt), 12-15 % of a 512-channel 3x3 tile and over half of a K = 512 1x1 tile.
+      const int mrow = m0 + qa * 128 + wave;
+      const long long ooff = obo + (long long)mrow * d.ldo + mycol;
+      const long long ostep = 8 * d.ldo;
+      bf16_t* op = out16 + ooff;
+      bf16_t* pp = pre16 ? pre16 + ooff : nullptr;
+      const char* cp = Ct + wave * 1024;
+      auto trip = [&](auto silu_c, int it) {
+        constexpr bool SILU = decltype(silu_c)::value;
+        const int row = it * 8 + wave;
+        f32x4 v = *(const f32x4*)(cp + it * 8192 + ((cq ^ (row & 15)) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+        if (mrow + it * 8 < d.M && col_ok) {
+          if (pp) {
+            u16x4 zo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) zo[e] = f2bf(v[e]);
+            *(u16x4*)(pp + it * ostep) = zo;
+          }
+          if constexpr (SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = sdm_silu(v[e]);
+          }
+          u16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+          *(u16x4*)(op + it * ostep) = o;
+          if (L.gn_stats) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float rr = bf2f(o[e]);
+              gs[e] += rr;
+              gq[e] = fmaf(rr, rr, gq[e]);
+            }
+          }
+        }
+      };
+      if (d.act == SDM_ACT_SILU) {
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) trip(std::true_type(), it);
+      } else {
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) trip(std::false_type(), it);
+      }
+      continue;
+    }
 #pragma unroll 2
     for (int it = 0; it < 16; ++it) {
       const int row = it * 8 + wave;            // tile row inside the slab: one row per wave and iteration
@@ -547,6 +622,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
       atomicAdd(dst + 1, b);
     }
   }
+  T8_STAMP(4);
 }
 
 int sdm_launch_igemm8_bf16(const BfLaunch& L0, int ntm, hipStream_t st) {
@@ -559,6 +635,8 @@ int sdm_launch_igemm8_bf16(const BfLaunch& L0, int ntm, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)igemm8_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  static const char* se_s = getenv("SDM_IGEMM8_SIMPLE_EPI");  // "0": the general epilogue loop everywhere (A/B)
+  L.no_simple_epi = (se_s && se_s[0] == '0') ? 1 : 0;
   static const char* tapin_s = getenv("SDM_BF16_TAPIN");     // "1": taps innermost in the K walk (see the kernel)
   const bool tapin = tapin_s && tapin_s[0] == '1';
   dim3 grid(ntm * L.ntn, L.d.nphase, L.d.batch);
