@@ -529,6 +529,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 cmul4 = (d.col_mul && mycol < N) ? *(const f32x4*)(d.col_mul + (long long)blockIdx.z * d.colvec_bs + mycol)
                                                  : f32x4{1.f, 1.f, 1.f, 1.f};
+    const bool simple_epi = !d.col_shift && !L.out_f32 && d.alpha == 1.0f && (d.act == SDM_ACT_NONE || d.act == SDM_ACT_SILU) &&
+                            !L.no_simple_epi;
+    const bool extras = res16 || res216 || dz16;
 #pragma unroll
     for (int sl = 0; sl < SL; ++sl) {
       __syncthreads();                       // every wave is done with the last K-step's fragments / the previous slab
@@ -542,6 +545,73 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
             Ct[prow * BN + wn * TN * 32 + j * 32 + l31] = acc[sl * TMS + ii][j][r];
           }
       __syncthreads();
+      if (simple_epi) {
+        // straight-line form of the loop below (alpha = 1, act in {none, SiLU}, bf16 output, no column factors): the thread's
+        // column quad is fixed, option addresses only where the option is present (see conv3_row_bf16_kernel / igemm8)
+        const int c4 = (tid % C4) * 4, pr0 = tid / C4;
+        constexpr int TRIPS = (BM / SL) * C4 / NT;
+        static_assert(((BM / SL) * C4) % NT == 0, "whole trips");
+        if (mycol < N) {
+          auto trip = [&](auto silu_c, int k) {
+            constexpr bool SILU = decltype(silu_c)::value;
+            const int prow = pr0 + k * (NT / C4);
+            const int row = SL == 1 ? prow : (prow / (TMS * 32)) * (TM * 32) + sl * (TMS * 32) + prow % (TMS * 32);
+            const long long orow = s_orow[row];
+            if (orow >= 0) {
+              f32x4 v = *(const f32x4*)(Ct + prow * BN + c4);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] += bias4[q];
+              if (pre16) {
+                u16x4 zo;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zo[q] = f2bf(v[q]);
+                *(u16x4*)(pre16 + obo + orow * d.ldo + mycol) = zo;
+              }
+              if constexpr (SILU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = sdm_silu(v[q]);
+              }
+              if (extras) {
+                if (res16) {
+                  const u16x4 rv = *(const u16x4*)(res16 + rbo + orow * d.ldres + mycol);
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) v[q] += bf2f(rv[q]);
+                }
+                if (res216) {
+                  const u16x4 rv = *(const u16x4*)(res216 + orow * d.ldres2 + mycol);
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) v[q] += bf2f(rv[q]);
+                }
+                if (dz16 && (d.dact_ncols == 0 || mycol < d.dact_ncols)) {
+                  const u16x4 zv = *(const u16x4*)(dz16 + orow * d.ldz + mycol);
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) v[q] *= sdm_dsilu(bf2f(zv[q]));
+                }
+              }
+              u16x4 o;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] = f2bf(v[q]);
+              *(u16x4*)(out16 + obo + orow * d.ldo + mycol) = o;
+              if (L.gn_stats) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const float r = bf2f(o[q]);
+                  gs[q] += r;
+                  gq[q] = fmaf(r, r, gq[q]);
+                }
+              }
+            }
+          };
+          if (d.act == SDM_ACT_SILU) {
+#pragma unroll 4
+            for (int k = 0; k < TRIPS; ++k) trip(std::true_type(), k);
+          } else {
+#pragma unroll 4
+            for (int k = 0; k < TRIPS; ++k) trip(std::false_type(), k);
+          }
+        }
+        continue;
+      }
 #pragma unroll 2
       for (int e = tid; e < (BM / SL) * C4; e += NT) {
         const int prow = e / C4, c4 = (e - prow * C4) * 4;
@@ -693,6 +763,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16_kernel(const BfLaunch
 struct RowLaunch {
   sdm_igemm_desc d;
   int ntn, W, wmask, gn_stats;
+  int no_simple_epi;    // SDM_IGEMM8_SIMPLE_EPI=0: the general epilogue loop (A/B)
   int dy[3];            // kernel-row offsets in the order they are walked
   int tapw[3][3];       // weight tap index of (row index, dx = -1, 0, +1)
 };
@@ -864,6 +935,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_ro
   f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
   const int mycol = n0 + (tid % C4) * 4;           // a thread keeps its column quad over all its rows: bias loaded once
   const f32x4 bias4 = (d.bias && mycol < N) ? *(const f32x4*)(d.bias + mycol) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool simple_epi = d.alpha == 1.0f && (d.act == SDM_ACT_NONE || d.act == SDM_ACT_SILU) && !L.no_simple_epi;
+  const bool extras = res16 || res216 || dz16;
 #pragma unroll
   for (int sl = 0; sl < SL; ++sl) {
     __syncthreads();
@@ -877,6 +950,72 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_ro
           Ct[prow_ * BN + wn * TN * 32 + j * 32 + l31] = acc[sl * TMS + ii][j][r];
         }
     __syncthreads();
+    if (simple_epi) {
+      // straight-line form of the loop below for alpha = 1 and act in {none, SiLU} (every conv of the U-Net): the thread's
+      // column quad is fixed, rows advance by NT / C4 per trip, option addresses are taken only where the option is present
+      // (the general loop is ~100 instructions per trip; same change and measurements as igemm8's, profiles/r04_igemm8_epi_ab.txt)
+      const int c4 = (tid % C4) * 4, pr0 = tid / C4;
+      constexpr int TRIPS = (BM / SL) * C4 / NT;
+      static_assert(((BM / SL) * C4) % NT == 0, "whole trips");
+      if (mycol < N) {
+        auto trip = [&](auto silu_c, int k) {
+          constexpr bool SILU = decltype(silu_c)::value;
+          const int prow_ = pr0 + k * (NT / C4);
+          const int row = SL == 1 ? prow_ : (prow_ / (TMS * 32)) * (TM * 32) + sl * (TMS * 32) + prow_ % (TMS * 32);
+          const long long orow = m0 + row;
+          f32x4 v = *(const f32x4*)(Ct + prow_ * BN + c4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += bias4[q];
+          if (pre16) {
+            u16x4 zo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zo[q] = f2bf(v[q]);
+            *(u16x4*)(pre16 + orow * d.ldo + mycol) = zo;
+          }
+          if constexpr (SILU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = sdm_silu(v[q]);
+          }
+          if (extras) {
+            if (res16) {
+              const u16x4 rv = *(const u16x4*)(res16 + orow * d.ldres + mycol);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] += bf2f(rv[q]);
+            }
+            if (res216) {
+              const u16x4 rv = *(const u16x4*)(res216 + orow * d.ldres2 + mycol);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] += bf2f(rv[q]);
+            }
+            if (dz16 && (d.dact_ncols == 0 || mycol < d.dact_ncols)) {
+              const u16x4 zv = *(const u16x4*)(dz16 + orow * d.ldz + mycol);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] *= sdm_dsilu(bf2f(zv[q]));
+            }
+          }
+          u16x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = f2bf(v[q]);
+          *(u16x4*)(out16 + orow * d.ldo + mycol) = o;
+          if (L.gn_stats) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float r = bf2f(o[q]);
+              gs[q] += r;
+              gq[q] = fmaf(r, r, gq[q]);
+            }
+          }
+        };
+        if (d.act == SDM_ACT_SILU) {
+#pragma unroll 4
+          for (int k = 0; k < TRIPS; ++k) trip(std::true_type(), k);
+        } else {
+#pragma unroll 4
+          for (int k = 0; k < TRIPS; ++k) trip(std::false_type(), k);
+        }
+      }
+      continue;
+    }
 #pragma unroll 2
     for (int e = tid; e < (BM / SL) * C4; e += NT) {
       const int prow_ = e / C4, c4 = (e - prow_ * C4) * 4;
@@ -1128,6 +1267,8 @@ static int launch_row(const sdm_igemm_desc* d, RowLaunch& R, int gn_stats, hipSt
   R.d = *d;
   R.ntn = cdiv(d->N, BN);
   R.gn_stats = gn_stats;
+  static const char* se_s = getenv("SDM_IGEMM8_SIMPLE_EPI");
+  R.no_simple_epi = (se_s && se_s[0] == '0') ? 1 : 0;
   {
     const double images = (double)d->M / ((double)d->Ht * d->Wt);
     const double in_b = images * d->a.H * d->a.W * d->K, w_b = (double)d->K * d->N * 9, out_b = images * d->Ho * d->Wo * d->N;
@@ -1259,6 +1400,8 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
   const bool xs = fast && !(xs_s && xs_s[0] == '0');
   static const char* pp_s = getenv("SDM_BF16_PP");         // 8-wave tiles: ping-pong of the two 4-wave halves ("0": off)
   L.pp = (pp_s && pp_s[0] == '1') ? 1 : 0;
+  static const char* se_s = getenv("SDM_IGEMM8_SIMPLE_EPI");   // "0": the general epilogue loops everywhere (A/B)
+  L.no_simple_epi = (se_s && se_s[0] == '0') ? 1 : 0;
   if (cfg == 0) rc = fast ? (xs ? launch_bf<128, 128, 2, 2, 2, true, true>(L, ntm, st) : launch_bf<128, 128, 2, 2, 2, true>(L, ntm, st))
                           : launch_bf<128, 128, 2, 2, 2, false>(L, ntm, st);
   else if (cfg == 1) {

@@ -473,8 +473,9 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
   const f32x4 cmul4 = (d.col_mul && col_ok) ? *(const f32x4*)(d.col_mul + (long long)blockIdx.z * d.colvec_bs + mycol) : one4;
   f32x4 gs = zero4, gq = zero4;                // GroupNorm statistics of this thread's 4 columns (over its rows)
   char* Ct = smem8;
-  const bool simple = !d.col_shift && !res16 && !res216 && !dz16 && !L.out_f32 && L.plain_out && d.alpha == 1.0f &&
+  const bool simple = !d.col_shift && !L.out_f32 && L.plain_out && d.alpha == 1.0f &&
                       (d.act == SDM_ACT_NONE || d.act == SDM_ACT_SILU) && !L.no_simple_epi;
+  const bool extras = res16 || res216 || dz16;                      // (uniform: one scalar branch per trip when absent)
 #pragma unroll
   for (int qa = 0; qa < 2; ++qa) {
     if (qa) __syncthreads();                   // slab 0 has been read
@@ -490,8 +491,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
         }
     __syncthreads();
     if (simple) {
-      // the forward conv's epilogue (bias, SiLU or nothing, bf16 rows in tile order, optional pre-activation copy and
-      // GroupNorm sums) as a straight loop: output pointers advance by 8 rows per trip, no table lookups, no per-option
+      // the forward conv's and the stride-1 data gradient's epilogue (bias, SiLU or nothing, bf16 rows in tile order, optional
+      // pre-activation copy, GroupNorm sums, residuals and the silu'(z) factor) as a straight loop: output pointers advance by 8 rows per trip, no table lookups, no per-option
       // address arithmetic -- the general loop below is ~200 instructions per trip and took 17-22 us per tile
       // (profiles/r04_igemm8_timing.txt), 12-15 % of a 512-channel 3x3 tile and over half of a K = 512 1x1 tile.
       const int mrow = m0 + qa * 128 + wave;
@@ -499,6 +500,9 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
       const long long ostep = 8 * d.ldo;
       bf16_t* op = out16 + ooff;
       bf16_t* pp = pre16 ? pre16 + ooff : nullptr;
+      // (data-gradient extras -- + residual, + second residual, x silu'(z), in the general loop's order -- take their addresses
+      // per trip: pointers kept across the loop spilled registers)
+      const bool zcol = d.dact_ncols == 0 || mycol < d.dact_ncols;
       const char* cp = Ct + wave * 1024;
       auto trip = [&](auto silu_c, int it) {
         constexpr bool SILU = decltype(silu_c)::value;
@@ -516,6 +520,24 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
           if constexpr (SILU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = sdm_silu(v[e]);
+          }
+          if (extras) {
+            const long long r = mrow + it * 8;
+            if (res16) {
+              const u16x4 rv = *(const u16x4*)(res16 + rbo + r * d.ldres + mycol);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += bf2f(rv[e]);
+            }
+            if (res216) {
+              const u16x4 rv = *(const u16x4*)(res216 + r * d.ldres2 + mycol);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += bf2f(rv[e]);
+            }
+            if (dz16 && zcol) {
+              const u16x4 zv = *(const u16x4*)(dz16 + r * d.ldz + mycol);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= sdm_dsilu(bf2f(zv[e]));
+            }
           }
           u16x4 o;
 #pragma unroll
