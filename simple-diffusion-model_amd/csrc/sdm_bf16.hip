@@ -28,6 +28,22 @@ static inline int ilog2_exact_bf(long v) {
 
 __device__ float g_zero_chunk_bf[4];
 
+// timing build only (-DSDM_IGEMM8_TIMING, see sdm_igemm8.hip): phase stamps of conv3_row_bf16_kernel's workgroups
+#ifdef SDM_IGEMM8_TIMING
+#define TR_MAXWG 65536
+__device__ unsigned long long g_tr[TR_MAXWG][4];
+#define TR_STAMP(i)                                                                                          \
+  do {                                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < TR_MAXWG) g_tr[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime();   \
+  } while (0)
+extern "C" int sdm_debug_row_times(unsigned long long* host, int nwg) {
+  if (nwg > TR_MAXWG) nwg = TR_MAXWG;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tr), (size_t)nwg * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#else
+#define TR_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ int xcd_contiguous_bf(int bid, int total) {   // see sdm_igemm.hip
   const int q = total >> 3, r = total & 7, x = bid & 7, i = bid >> 3;
   return x < r ? x * (q + 1) + i : r * (q + 1) + (x - r) * q + i;
@@ -780,6 +796,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_ro
   constexpr int BIT = BN / (8 * NWAVE);                   // weight-tile DMA instructions per wave (BN rows of 128 B)
   constexpr int BSTAGE = BN * 128;
   extern __shared__ __align__(16) char smem_r[];
+  TR_STAMP(0);
   char* Pb = smem_r;                                      // 2 patch buffers
   char* Bs = smem_r + 2 * PBYTES;                         // 2 weight stages
 
@@ -871,6 +888,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_ro
 
   __syncthreads();
   const int NP = 3 * KC;                                    // patches: (kernel row, chunk), chunk fastest
+  TR_STAMP(1);
   issue_patch(0, 0, 0);
   issue_b(0, 0, 0, 0);
   int ri = 0, kc = 0;                                       // (kernel row, chunk) of the patch being computed
@@ -920,6 +938,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_ro
   }
 
   // ---- epilogue (the vector epilogue of igemm_bf16_kernel; output row of tile row r is m0 + r)
+  TR_STAMP(2);
   bf16_t* out16 = (bf16_t*)d.out;
   bf16_t* pre16 = (bf16_t*)d.out_preact;
   const bf16_t* res16 = (const bf16_t*)d.res;
@@ -1083,6 +1102,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_ro
       atomicAdd(dst + 1, b);
     }
   }
+  TR_STAMP(3);
 }
 
 // finishes a split-K contraction (ws [batch entry][out row][N] raw fp32 sums, left zero-filled); rows = per entry
