@@ -784,7 +784,7 @@ struct RowLaunch {
   int tapw[3][3];       // weight tap index of (row index, dx = -1, 0, +1)
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NBS = 2>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_row_bf16_kernel(const RowLaunch L) {
   const sdm_igemm_desc& d = L.d;
   constexpr int NT = 64 * WM * WN, NWAVE = WM * WN;
@@ -798,10 +798,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_ro
   extern __shared__ __align__(16) char smem_r[];
   TR_STAMP(0);
   char* Pb = smem_r;                                      // 2 patch buffers
-  char* Bs = smem_r + 2 * PBYTES;                         // 2 weight stages
+  char* Bs = smem_r + 2 * PBYTES;                         // NBS weight stages
+  // NBS > 2 (the 8-wave 256x128 tile): the weight stage of K-step s + NBS - 1 is issued in K-step s, the wait in front of a
+  // barrier is COUNTED (only the stage the coming step reads must have landed), and the fragment reads are inline asm -- next to
+  // LDS-DMA the compiler puts s_waitcnt vmcnt(0) in front of every builtin LDS read (§4d), which would drain the ring each step.
+  constexpr int DB = NBS - 1;                             // weight stages in flight behind the one being waited for + 1
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
+  // (Persistent workgroups -- a grid of the resident slots, each walking several tiles -- were built and measured neutral,
+  // 771 vs 771 TFLOP/s at 128 x 128x128 x 128 channels, profiles/r04_row_persist_ab.txt: with two workgroups per CU the hand-over
+  // between workgroups is already hidden by the neighbour.  Not kept: 30 more registers and 60 spilled scalars.)
   const int tile_id = xcd_contiguous_bf(blockIdx.x, gridDim.x);
   const int tile_n = tile_id % L.ntn, tile_m = tile_id / L.ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -889,8 +896,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_ro
   __syncthreads();
   const int NP = 3 * KC;                                    // patches: (kernel row, chunk), chunk fastest
   TR_STAMP(1);
+  const int S = 3 * NP;                                     // K-steps (= weight stages): step s = patch s / 3, column tap s % 3
+  auto issue_stage = [&](int s2) {                          // weight stage of K-step s2 (if it exists) into slot s2 % NBS
+    if (s2 < S) {
+      const int pj = s2 / 3, dxj = s2 - pj * 3;
+      const int rj = pj / KC, kj = pj - rj * KC;
+      issue_b(rj, dxj, kj, s2 % NBS);
+    }
+  };
   issue_patch(0, 0, 0);
-  issue_b(0, 0, 0, 0);
+  if constexpr (NBS > 2) {
+#pragma unroll
+    for (int j = 0; j < DB; ++j) issue_stage(j);
+  } else {
+    issue_b(0, 0, 0, 0);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem_r;
   int ri = 0, kc = 0;                                       // (kernel row, chunk) of the patch being computed
   for (int pi = 0; pi < NP; ++pi) {
     int nri = ri, nkc = kc + 1;                             // ... of the next patch
@@ -899,12 +920,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_ro
 #pragma unroll
     for (int dxi = 0; dxi < 3; ++dxi) {
       const int s = pi * 3 + dxi;
-      wait_vmcnt_bf<0>();
+      if constexpr (NBS > 2) {
+        // issue order inside a step: [next patch if dxi == 0], weight stage s + DB.  Behind the stage this step reads (issued
+        // DB steps ago) lie DB - 1 weight stages (BIT instructions each) and, if one of the steps s - DB + 1 .. s - 1 was a
+        // dxi == 0 step, that step's patch (>= 4 instructions per wave: PINST = 17 or 33 over 4 or 8 waves).
+        constexpr int PMIN = PINST / NWAVE;
+        const bool patch_behind = (DB == 2) ? (dxi == 1) : (dxi == 1 || dxi == 2);     // (dxi is a constant after unrolling)
+        if (s + DB >= S) wait_vmcnt_bf<0>();
+        else if (patch_behind) wait_vmcnt_bf<(DB - 1) * BIT + PMIN>();
+        else wait_vmcnt_bf<(DB - 1) * BIT>();
+      } else {
+        wait_vmcnt_bf<0>();
+      }
       __builtin_amdgcn_s_barrier();                         // stage s (and patch pi) visible; stage s - 1 / patch pi - 1 free
-      if (dxi < 2) issue_b(ri, dxi + 1, kc, (s + 1) & 1);
-      else if (pi + 1 < NP) issue_b(nri, 0, nkc, (s + 1) & 1);
-      if (dxi == 0 && pi + 1 < NP) issue_patch(nri, nkc, (pi + 1) & 1);
-      const char* Bq = Bs + (s & 1) * BSTAGE;
+      if constexpr (NBS > 2) {
+        if (dxi == 0 && pi + 1 < NP) issue_patch(nri, nkc, (pi + 1) & 1);
+        issue_stage(s + DB);
+      } else {
+        if (dxi < 2) issue_b(ri, dxi + 1, kc, (s + 1) & 1);
+        else if (pi + 1 < NP) issue_b(nri, 0, nkc, (s + 1) & 1);
+        if (dxi == 0 && pi + 1 < NP) issue_patch(nri, nkc, (pi + 1) & 1);
+      }
+      const char* Bq = Bs + (s % NBS) * BSTAGE;
       f32x4 af[2][TM], bf[2][TN];
       int aoff[TM];                                         // (the chunk swizzle (q >> 1) & 7 is bits 8..10 of q * 128)
 #pragma unroll
@@ -912,6 +949,43 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_ro
         const bool dead = dxi == 0 ? (deadm >> (2 * i)) & 1u : (dxi == 2 ? (deadm >> (2 * i + 1)) & 1u : false);
         aoff[i] = dead ? -128 : t128[i] + dxi * 128;
       }
+      if constexpr (NBS > 2) {
+        const unsigned pq0 = lds0 + (unsigned)(Pq - smem_r), bq0 = lds0 + (unsigned)(Bq - smem_r);
+        auto ldfrag_asm = [&](int kg, int st) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const unsigned ad = pq0 + (unsigned)(aoff[i] + (((kg * 2 + h) ^ ((aoff[i] >> 8) & 7)) << 4));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(af[st][i]) : "v"(ad) : "memory");
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const unsigned ad = bq0 + (unsigned)(boff[j] + (((kg * 2 + h) ^ sw_b) << 4));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bf[st][j]) : "v"(ad) : "memory");
+          }
+        };
+        ldfrag_asm(0, 0);
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+          if (kg < 3) {
+            ldfrag_asm(kg + 1, (kg + 1) & 1);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");   // the set read one trip ago has landed
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[kg & 1][i]));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bf[kg & 1][j]));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[kg & 1][i]),
+                                                                  __builtin_bit_cast(bf16x8, bf[kg & 1][j]), acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
       auto ldfrag = [&](int kg, int st) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -932,10 +1006,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_ro
                                                                 __builtin_bit_cast(bf16x8, bf[kg & 1][j]), acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+      }
     }
     ri = nri;
     kc = nkc;
   }
+  if constexpr (NBS > 2) __syncthreads();      // (asm reads: every wave is done with the ring before the epilogue reuses it)
 
   // ---- epilogue (the vector epilogue of igemm_bf16_kernel; output row of tile row r is m0 + r)
   TR_STAMP(2);
@@ -944,7 +1020,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv3_ro
   const bf16_t* res16 = (const bf16_t*)d.res;
   const bf16_t* res216 = (const bf16_t*)d.res2;
   const bf16_t* dz16 = (const bf16_t*)d.dact_z;
-  constexpr size_t LDSB = (size_t)2 * PBYTES + 2 * BSTAGE;
+  constexpr size_t LDSB = (size_t)2 * PBYTES + NBS * BSTAGE;
   constexpr int SL = ((size_t)BM * BN * 4 <= LDSB) ? 1 : 2;
   constexpr int TMS = TM / SL;
   static_assert(TM % SL == 0 && (size_t)(BM / SL) * BN * 4 <= LDSB, "output slab must fit");
@@ -1274,12 +1350,12 @@ static int row_tile(const sdm_igemm_desc* d, int out_f32, int vec_epi, RowLaunch
   return 128;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NBS = 2>
 static int launch_row(const sdm_igemm_desc* d, RowLaunch& R, int gn_stats, hipStream_t st) {
   constexpr int PINST = (BM + 2 + 7) / 8;
-  constexpr size_t lds = (size_t)2 * (128 + PINST * 1024) + (size_t)2 * BN * 128;
+  constexpr size_t lds = (size_t)2 * (128 + PINST * 1024) + (size_t)NBS * BN * 128;
   static bool attr_set = false;
-  auto kern = conv3_row_bf16_kernel<BM, BN, WM, WN>;
+  auto kern = conv3_row_bf16_kernel<BM, BN, WM, WN, NBS>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
@@ -1408,8 +1484,11 @@ extern "C" int sdm_igemm_bf16(const sdm_igemm_desc* d, int out_f32, sdm_stream_t
       // TFLOP/s at 128 x 128x128, 761 vs 772 at 32 x 256x256, profiles/r04_row256_ab.txt): the row kernel is paced by its
       // one-barrier-per-K-step schedule, not by the feed.  Parity-tested (tests: row_patch ... forced), off by default.
       static const char* r256 = getenv("SDM_BF16_ROW256");
-      const bool tall = d->N <= 128 && ((long)d->a.H * d->a.W) % 256 == 0 && d->M / 256 >= 512 && r256 && r256[0] == '1';
-      rc = tall ? launch_row<256, 128, 4, 2>(d, R, gs, st) : launch_row<128, 128, 2, 2>(d, R, gs, st);
+      const bool tall = d->N <= 128 && ((long)d->a.H * d->a.W) % 256 == 0 && d->M / 256 >= 512 && r256 && r256[0] >= '1';
+      // "3" / "4": the same tile with a 3- / 4-slot weight ring, counted waits and asm fragment reads
+      if (tall && r256[0] == '3') rc = launch_row<256, 128, 4, 2, 3>(d, R, gs, st);
+      else if (tall && r256[0] == '4') rc = launch_row<256, 128, 4, 2, 4>(d, R, gs, st);
+      else rc = tall ? launch_row<256, 128, 4, 2>(d, R, gs, st) : launch_row<128, 128, 2, 2>(d, R, gs, st);
       if (rc != SDM_OK) return rc;
       return gs ? SDM_STATS_DONE : SDM_OK;
     }

@@ -363,7 +363,7 @@ def test_row_patch_kernel_forced():
     import sys
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    env = dict(os.environ, SDM_BF16_ROW="1", SDM_BF16_ROW256="1")     # (and the opt-in 256x128 tile where it is eligible)
+    env = dict(os.environ, SDM_BF16_ROW="1", SDM_BF16_ROW256="3")     # (and the opt-in 256x128 tile, deep weight ring, where eligible)
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_bf16.py"),
                         os.path.join(here, "test_gpu_bf16_train.py"), "-q", "-x", "-k",
