@@ -373,6 +373,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmLaunch L) {
 // --------------------------------------------------------------------------------------------
 __device__ float g_zero_chunk[4];
 
+// timing build only (-DSDM_IGEMM8_TIMING, see sdm_igemm8.hip): phase stamps of igemm_glds_kernel's workgroups (fp32)
+#ifdef SDM_IGEMM8_TIMING
+#define TF_MAXWG 65536
+__device__ unsigned long long g_tf[TF_MAXWG][4];
+#define TF_STAMP(i)                                                                                                            \
+  do {                                                                                                                         \
+    const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                                       \
+    if (threadIdx.x == 0 && wg_ < TF_MAXWG) g_tf[wg_][i] = __builtin_amdgcn_s_memrealtime();                                    \
+  } while (0)
+extern "C" int sdm_debug_f32_clear() {
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tf)) != hipSuccess) return -1;
+  return hipMemset(p, 0, sizeof(g_tf)) == hipSuccess ? 0 : -1;
+}
+extern "C" int sdm_debug_f32_times(unsigned long long* host, int nwg) {
+  if (nwg > TF_MAXWG) nwg = TF_MAXWG;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tf), (size_t)nwg * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#else
+#define TF_STAMP(i) do { } while (0)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -396,6 +418,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
   float* Bs = smem + NBUF * A_TILE;
   long long* s_orow = (long long*)(Bs + NBUF * B_TILE);
   int* s_tap = (int*)(s_orow + BM);
+  TF_STAMP(0);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
@@ -454,6 +477,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
       a_ys[i] = -(1 << 20); a_xs[i] = 0; a_base[i] = 0;
     }
   }
+  TF_STAMP(1);
   __syncthreads();   // s_orow / s_tap visible
 
   const int ntap = d.ntaps[phase];
@@ -593,6 +617,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
   }
 
   // ---- epilogue (same contract as igemm_kernel)
+  TF_STAMP(2);
   if (L.splitk > 1) {       // partial sums: nothing but the atomics
     float* wsb = d.ws + (long long)blockIdx.z * L.out_rows * N;
 #pragma unroll
@@ -607,6 +632,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
           if (orow >= 0) atomicAdd(wsb + orow * N + col, acc[i][j][r]);
         }
       }
+    TF_STAMP(3);
     return;
   }
   const long long obo = b0 * d.o_bs0 + b1 * d.o_bs1;
@@ -638,6 +664,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmLaunch L) {
       }
     }
   }
+  TF_STAMP(3);
 }
 
 template <int BM, int BN, int WM, int WN, bool BKM, int NBUF, int BKT>
