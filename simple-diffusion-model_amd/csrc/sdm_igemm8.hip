@@ -473,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
   const f32x4 cmul4 = (d.col_mul && col_ok) ? *(const f32x4*)(d.col_mul + (long long)blockIdx.z * d.colvec_bs + mycol) : one4;
   f32x4 gs = zero4, gq = zero4;                // GroupNorm statistics of this thread's 4 columns (over its rows)
   char* Ct = smem8;
-  const bool simple = !d.col_shift && !L.out_f32 && L.plain_out && d.alpha == 1.0f &&
+  const bool simple = !d.col_shift && !L.out_f32 && d.alpha == 1.0f &&
                       (d.act == SDM_ACT_NONE || d.act == SDM_ACT_SILU) && !L.no_simple_epi;
   const bool extras = res16 || res216 || dz16;                      // (uniform: one scalar branch per trip when absent)
 #pragma unroll
@@ -495,11 +495,9 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
       // pre-activation copy, GroupNorm sums, residuals and the silu'(z) factor) as a straight loop: output pointers advance by 8 rows per trip, no table lookups, no per-option
       // address arithmetic -- the general loop below is ~200 instructions per trip and took 17-22 us per tile
       // (profiles/r04_igemm8_timing.txt), 12-15 % of a 512-channel 3x3 tile and over half of a K = 512 1x1 tile.
+      // (output row of a tile row: the row itself for plain geometry, else the table entry -- sub-pixel phases, strided outputs)
       const int mrow = m0 + qa * 128 + wave;
-      const long long ooff = obo + (long long)mrow * d.ldo + mycol;
-      const long long ostep = 8 * d.ldo;
-      bf16_t* op = out16 + ooff;
-      bf16_t* pp = pre16 ? pre16 + ooff : nullptr;
+      const long long ooff = obo + mycol;
       // (data-gradient extras -- + residual, + second residual, x silu'(z), in the general loop's order -- take their addresses
       // per trip: pointers kept across the loop spilled registers)
       const bool zcol = d.dact_ncols == 0 || mycol < d.dact_ncols;
@@ -510,19 +508,20 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
         f32x4 v = *(const f32x4*)(cp + it * 8192 + ((cq ^ (row & 15)) << 4));
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += bias4[e];
-        if (mrow + it * 8 < d.M && col_ok) {
-          if (pp) {
+        const long long r = L.plain_out ? (long long)(mrow + it * 8) : s_orow[qa * 128 + row];
+        if ((L.plain_out ? mrow + it * 8 < d.M : r >= 0) && col_ok) {
+          const long long oo = ooff + r * d.ldo;
+          if (pre16) {
             u16x4 zo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) zo[e] = f2bf(v[e]);
-            *(u16x4*)(pp + it * ostep) = zo;
+            *(u16x4*)(pre16 + oo) = zo;
           }
           if constexpr (SILU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = sdm_silu(v[e]);
           }
           if (extras) {
-            const long long r = mrow + it * 8;
             if (res16) {
               const u16x4 rv = *(const u16x4*)(res16 + rbo + r * d.ldres + mycol);
 #pragma unroll
@@ -542,7 +541,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_bf16_kernel(const BfLaunch L) {
           u16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-          *(u16x4*)(op + it * ostep) = o;
+          *(u16x4*)(out16 + oo) = o;
           if (L.gn_stats) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
