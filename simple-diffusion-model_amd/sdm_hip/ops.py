@@ -115,8 +115,26 @@ class _SideStream:
     def stream(self, device):
         st = self.streams.get(device)
         if st is None:
-            st = self.streams[device] = torch.cuda.Stream(device=device)
+            st = self.streams[device] = self._masked_stream(device) or torch.cuda.Stream(device=device)
         return st
+
+    @staticmethod
+    def _masked_stream(device):
+        """SDM_WGRAD_CUS=n (experiment switch, default off): the side stream's queue may use only the first n bits of the CU mask
+        (hipExtStreamCreateWithCUMask), so the weight gradients leave the other CUs to the forward / data-gradient chain.
+        Measured on the headline and the C4 bf16 step: profiles/r04_wgrad_cumask.txt."""
+        import os
+        n = int(os.environ.get("SDM_WGRAD_CUS", "0") or 0)
+        if n <= 0:
+            return None
+        hip = C.CDLL("libamdhip64.so")
+        words = (C.c_uint32 * 8)(*[(0xFFFFFFFF if n >= 32 * (i + 1) else ((1 << max(0, n - 32 * i)) - 1)) for i in range(8)])
+        raw = C.c_void_p()
+        with torch.cuda.device(device):
+            rc = hip.hipExtStreamCreateWithCUMask(C.byref(raw), 8, words)
+        if rc != 0 or not raw.value:
+            raise lib.SdmError(f"SDM_WGRAD_CUS={n}: hipExtStreamCreateWithCUMask failed (hip error {rc})")
+        return torch.cuda.ExternalStream(raw.value, device=device)
 
     def fork(self, *tensors):
         """Tensors read on the side stream are kept referenced until join(): their memory cannot be handed out again
