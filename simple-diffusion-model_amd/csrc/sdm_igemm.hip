@@ -1005,7 +1005,9 @@ static int skinny_splitk(const sdm_igemm_desc* d) {
 }
 
 struct TileCfg { int bm, bn; };
-static const TileCfg kCfgs[4] = {{128, 128}, {64, 64}, {32, 128}, {128, 64}};
+// index 4 is the weight-streaming kernel's marker (no tile of its own: entry unused); 5 = 64 x 128, the tile that spans all of N
+// on the 128-channel layers (12 B/clk/CU of LDS-DMA feed at the matrix peak against the 64x64 tile's 16: DESIGN section 7 item 4)
+static const TileCfg kCfgs[6] = {{128, 128}, {64, 64}, {32, 128}, {128, 64}, {64, 64}, {64, 128}};
 
 // Tile / split-K choice by a small cost model (cycles per CU): a workgroup spends `mfma` matrix-pipe cycles plus
 // `ovh` issue/barrier cycles per K-step; co-resident workgroups share the matrix pipe but hide each other's
@@ -1026,17 +1028,20 @@ static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* w
   // Calibrated on MI355X (profiles/r01_igemm_tile_sweep.txt): a CU retires roughly one workgroup K-step per
   // (matrix cycles + staging/issue overhead) whatever the co-residency (co-resident workgroups overlap ~8 %),
   // so big tiles win whenever the grid still covers the 256 CUs evenly.
-  static const double kMfma[4] = {4096, 1024, 1024, 2048};
-  static const double kOvh[4] = {3000, 900, 900, 1850};   // 128-row tiles charged +600: they co-run worse with the
-                                                           // weight-gradient stream (A/B on the training step)
-  static const int kOcc[4] = {2, 4, 3, 2};
+  static const double kMfma[6] = {4096, 1024, 1024, 2048, 0, 2048};
+  static const double kOvh[6] = {3000, 900, 900, 1850, 0, 1850};   // 128-row tiles charged +600: they co-run worse with the
+                                                                    // weight-gradient stream (A/B on the training step)
+  static const int kOcc[6] = {2, 4, 3, 2, 0, 2};
+  static const char* t5_s = getenv("SDM_IGEMM_TILE5");     // "1": the 64x128 tile takes part in the choice
   static const char* pen_s = getenv("SDM_IGEMM_BIGTILE_PENALTY");   // tuning aid: extra cycles charged to 128-row tiles
   const double pen = pen_s ? atof(pen_s) : 0.0;
   static const char* sc_s = getenv("SDM_IGEMM_SPLIT_COST");    // cycles charged to a split (finishing launch + atomic drain)
   const double split_cost = sc_s ? atof(sc_s) : 6000.0;
   double best = 1e300;
   int bc = 1, bs = 1;
-  for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < 6; ++c) {
+    if (c == 4 || (c == 5 && !(t5_s && t5_s[0] == '1'))) continue;
+    if (c == 5 && (M < 64 || N <= 64)) continue;
     if (c == 2 && M > 32) continue;
     if (c != 2 && M <= 32) continue;
     if ((c == 0 || c == 3) && M < 96) continue;
@@ -1056,7 +1061,7 @@ static void igemm_plan(const sdm_igemm_desc* d, int* cfg, int* splitk, size_t* w
   static const char* force = getenv("SDM_IGEMM_FORCE");
   if (force) {
     int fc = -1, fs = 1;
-    if (sscanf(force, "%d,%d", &fc, &fs) >= 1 && fc >= 0 && fc < 4) {
+    if (sscanf(force, "%d,%d", &fc, &fs) >= 1 && fc >= 0 && fc < 6 && fc != 4) {
       bc = fc;
       bs = (fs >= 1 && fs <= T) ? fs : 1;
     }
@@ -1174,6 +1179,7 @@ extern "C" int sdm_igemm(const sdm_igemm_desc* d, sdm_stream_t stream) {
   if (cfg == 0) rc = dispatch_igemm<128, 128, 2, 2>(L, ntm, km, vec, aff, st);
   else if (cfg == 1) rc = dispatch_igemm<64, 64, 2, 2>(L, ntm, km, vec, aff, st);
   else if (cfg == 2) rc = dispatch_igemm<32, 128, 1, 4>(L, ntm, km, vec, aff, st);
+  else if (cfg == 5) rc = dispatch_igemm<64, 128, 2, 2>(L, ntm, km, vec, aff, st);
   else rc = dispatch_igemm<128, 64, 2, 2>(L, ntm, km, vec, aff, st);
   if (rc != SDM_OK) return rc;
   if (finish && d->defer_epilogue) return SDM_DEFERRED;     // raw sums stay in ws: the caller's next kernel finishes them

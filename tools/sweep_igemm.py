@@ -1,4 +1,5 @@
-"""Tile/split-K sweep of the contraction kernel on representative U-Net shapes (tuning aid; MI355X only).
+"""Tile/split-K sweep of the contraction kernel on representative U-Net shapes (tuning aid; MI355X only):
+    python tools/sweep_igemm.py [cfgs e.g. 1,5] [split-K factors e.g. 1,2,4]
 Each configuration runs in a fresh subprocess because the override is read once per process."""
 import json
 import os
@@ -37,8 +38,10 @@ print(json.dumps(res))
 
 def main():
     out = {}
-    for cfg in (0, 1, 3):
-        for sk in (1, 2, 4, 8):
+    cfgs = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 3, 5]     # 5 = 64x128
+    sks = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
+    for cfg in cfgs:
+        for sk in sks:
             env = dict(os.environ, SDM_IGEMM_FORCE=f"{cfg},{sk}")
             r = subprocess.run([sys.executable, "-c", CHILD % (os.path.join(ROOT, "simple-diffusion-model_amd"), SHAPES)],
                                env=env, capture_output=True, text=True)
