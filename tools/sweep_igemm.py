@@ -36,7 +36,17 @@ for name, n, h, w, cin, cout, kind in %r:
 print(json.dumps(res))
 '''
 
+N1_SHAPES = [  # the weight-streaming launches of the N=1 sampling step (python tools/sweep_igemm.py 1,5 4,8,16,32 n1)
+    ("c512@16", 1, 16, 16, 512, 512, "c3s1"), ("c512@8", 1, 8, 8, 512, 512, "c3s1"), ("c1024@8", 1, 8, 8, 1024, 1024, "c3s1"),
+    ("c1024@16", 1, 16, 16, 1024, 1024, "c3s1"), ("c512@32", 1, 32, 32, 512, 512, "c3s1"), ("c256@32", 1, 32, 32, 256, 256, "c3s1"),
+    ("ct1024-512@8", 1, 8, 8, 1024, 512, "ct4"), ("ct1024-256@16", 1, 16, 16, 1024, 256, "ct4"),
+]
+
+
 def main():
+    global SHAPES
+    if len(sys.argv) > 3 and sys.argv[3] == "n1":
+        SHAPES = N1_SHAPES
     out = {}
     cfgs = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 3, 5]     # 5 = 64x128
     sks = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
