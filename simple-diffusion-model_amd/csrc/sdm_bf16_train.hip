@@ -15,7 +15,6 @@
 
 #define SDM_FAST_SIGMOID
 #include "sdm_bf16_int.h"
-#include "sdm_gn_bwd_fused.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -794,10 +793,9 @@ extern "C" int sdm_cast_bf16_t(const float* src, uint16_t* dst, int T, int R, in
 // 8 channels per lane (C % 8 == 0, C <= 2048); partials meet in LDS, one atomic pair per channel per workgroup
 __global__ __launch_bounds__(256) void gn_bwd_sums_bf16_kernel(const bf16_t* __restrict__ dout, long long lddo,
                                                                const bf16_t* __restrict__ y, long long ldy, int HW, int C,
-                                                               int rows_per_block, float* __restrict__ ws, int* __restrict__ ctr) {
+                                                               int rows_per_block, float* __restrict__ ws) {
   __shared__ float part[2][256][8];
   const int n = blockIdx.y;
-  if (ctr && blockIdx.x == 0 && threadIdx.x == 0) ctr[n] = 0;     // arrival counter of the fused apply pass (next launch)
   const int r0 = blockIdx.x * rows_per_block;
   int r1 = r0 + rows_per_block;
   if (r1 > HW) r1 = HW;
@@ -885,22 +883,9 @@ extern "C" int sdm_gn_adagn_bwd_bf16(const uint16_t* dout, int64_t lddo, const u
   hipStream_t st = (hipStream_t)s;
   int rpb = (HW + 63) / 64;
   if (rpb < 8) rpb = 8;
-  const bool fused = gn_bwd_fused_ok(C, groups, 8, GnbRow<true>::MAXC);
-  int* ctr = fused ? (int*)coef : nullptr;          // the first `images` words of the coefficient scratch (no contract on entry)
   SDM_LAUNCH(gn_bwd_sums_bf16_kernel, dim3(cdiv(HW, rpb), images), dim3(256), 0, st, dout, (long long)lddo, y,
-                     (long long)ldy, HW, C, rpb, ws, ctr);
+                     (long long)ldy, HW, C, rpb, ws);
   SDM_CHECK_LAUNCH("gn_bwd_sums_bf16");
-  if (fused) {
-    // coefficients rebuilt by every workgroup of the apply pass (sdm_gn_bwd_fused.h): ~1024 workgroups, each inside one image
-    int rpa = cdiv((long)images * HW, 2048);
-    const int rows_in_flight = 256 / (C / 8);        // one trip of a workgroup
-    if (rpa < 2 * rows_in_flight) rpa = 2 * rows_in_flight;
-    SDM_LAUNCH(gn_bwd_apply_fused_kernel<true>, dim3(cdiv(HW, rpa), images), dim3(256), 0, st, dout, (long long)lddo, y,
-                       (long long)ldy, z, (long long)ldz, ws, ctr, HW, C, groups, gamma, beta, mod, mod_nstride, mean, rstd, dz,
-                       (long long)lddz, dmod, dgamma, dbeta, rpa);
-    SDM_CHECK_LAUNCH("gn_bwd_apply_fused_bf16");
-    return SDM_OK;
-  }
   int rc = sdm_launch_gn_bwd_coef(ws, images, HW, C, groups, gamma, beta, mod, mod_nstride, mean, rstd, coef, dmod, dgamma,
                                   dbeta, st);
   if (rc != SDM_OK) return rc;

@@ -1,7 +1,6 @@
 // Bandwidth-bound kernels of the U-Net step: NCHW<->NHWC edge convs, GroupNorm/AdaGN folding,
 // column softmax, embedding MLP GEMVs, sampler updates, loss, fused Adam.  All wave64.
 #include "sdm_common.h"
-#include "sdm_gn_bwd_fused.h"
 
 // --------------------------------------------------------------------------------------------
 // Edge convolutions (3 or 6 image channels on one side).  The small channel count is a template parameter so that
@@ -523,9 +522,8 @@ extern "C" int sdm_affine_residual(const float* y, int64_t ldy, const float* sca
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const float* __restrict__ dout, long long lddo,
                                                           const float* __restrict__ y, long long ldy, int HW, int C,
-                                                          int rows_per_block, float* __restrict__ ws, int* __restrict__ ctr) {
+                                                          int rows_per_block, float* __restrict__ ws) {
   const int n = blockIdx.y;
-  if (ctr && blockIdx.x == 0 && threadIdx.x == 0) ctr[n] = 0;     // arrival counter of the fused apply pass (next launch)
   const int r0 = blockIdx.x * rows_per_block;
   int r1 = r0 + rows_per_block;
   if (r1 > HW) r1 = HW;
@@ -546,10 +544,9 @@ __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const float* __restric
 // 256/(C/4) lane groups walk different rows; partials meet in LDS, one atomic pair per channel per workgroup.
 __global__ __launch_bounds__(256) void gn_bwd_sums_vec_kernel(const float* __restrict__ dout, long long lddo,
                                                               const float* __restrict__ y, long long ldy, int HW, int C,
-                                                              int rows_per_block, float* __restrict__ ws, int* __restrict__ ctr) {
+                                                              int rows_per_block, float* __restrict__ ws) {
   __shared__ float part[2][256][4];
   const int n = blockIdx.y;
-  if (ctr && blockIdx.x == 0 && threadIdx.x == 0) ctr[n] = 0;     // arrival counter of the fused apply pass (next launch)
   const int r0 = blockIdx.x * rows_per_block;
   int r1 = r0 + rows_per_block;
   if (r1 > HW) r1 = HW;
@@ -687,26 +684,13 @@ extern "C" int sdm_gn_adagn_bwd(const float* dout, int64_t lddo, const float* y,
                    aligned16(dout) && aligned16(y) && aligned16(dz) && (z == nullptr || aligned16(z)) && aligned16(coef);
   int rpb = (HW + 63) / 64;
   if (rpb < 8) rpb = 8;
-  const bool fused = vec && gn_bwd_fused_ok(C, groups, 4, GnbRow<false>::MAXC);
-  int* ctr = fused ? (int*)coef : nullptr;          // the first `images` words of the coefficient scratch (no contract on entry)
   if (vec && C <= 1024)
     SDM_LAUNCH(gn_bwd_sums_vec_kernel, dim3(cdiv(HW, rpb), images), dim3(256), 0, st, dout, (long long)lddo, y,
-                       (long long)ldy, HW, C, rpb, ws, ctr);
+                       (long long)ldy, HW, C, rpb, ws);
   else
     SDM_LAUNCH(gn_bwd_sums_kernel, dim3(cdiv(HW, rpb), images), dim3(256), 0, st, dout, (long long)lddo, y,
-                       (long long)ldy, HW, C, rpb, ws, ctr);
+                       (long long)ldy, HW, C, rpb, ws);
   SDM_CHECK_LAUNCH("gn_bwd_sums");
-  if (fused) {
-    // coefficients rebuilt by every workgroup of the apply pass (sdm_gn_bwd_fused.h): ~1024 workgroups, each inside one image
-    int rpa = cdiv((long)images * HW, 2048);
-    const int rows_in_flight = 256 / (C / 4);        // one trip of a workgroup
-    if (rpa < 2 * rows_in_flight) rpa = 2 * rows_in_flight;
-    SDM_LAUNCH(gn_bwd_apply_fused_kernel<false>, dim3(cdiv(HW, rpa), images), dim3(256), 0, st, dout, (long long)lddo, y,
-                       (long long)ldy, z, (long long)ldz, ws, ctr, HW, C, groups, gamma, beta, mod, mod_nstride, mean, rstd, dz,
-                       (long long)lddz, dmod, dgamma, dbeta, rpa);
-    SDM_CHECK_LAUNCH("gn_bwd_apply_fused");
-    return SDM_OK;
-  }
   SDM_LAUNCH(gn_bwd_coef_kernel, dim3(images * groups), dim3(64), 0, st, ws, HW, C, groups, gamma, beta, mod,
                      mod_nstride, mean, rstd, coef, dmod, dgamma, dbeta);
   SDM_CHECK_LAUNCH("gn_bwd_coef");
