@@ -982,7 +982,17 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     const int ch = threadIdx.x % cl, rl = threadIdx.x / cl;
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (ch < C8) {
-      for (long long r = r0 + rl; r < r1; r += RL) {
+      long long r = r0 + rl;
+      for (; r + 7 * RL < r1; r += 8 * RL) {        // eight independent rows per trip: their loads overlap
+        u16x8 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *(const u16x8*)(x + (r + j * RL) * ldx + 8 * ch);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          a[k] += ((bf2f(v[0][k]) + bf2f(v[1][k])) + (bf2f(v[2][k]) + bf2f(v[3][k]))) +
+                  ((bf2f(v[4][k]) + bf2f(v[5][k])) + (bf2f(v[6][k]) + bf2f(v[7][k])));
+      }
+      for (; r < r1; r += RL) {
         const u16x8 v = *(const u16x8*)(x + r * ldx + 8 * ch);
 #pragma unroll
         for (int k = 0; k < 8; ++k) a[k] += bf2f(v[k]);
@@ -1007,7 +1017,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 }
 extern "C" int sdm_colsum_bf16(const uint16_t* x, int64_t ldx, int rows, int C, float* out, sdm_stream_t s) {
   SDM_CHECK_ARG(x && out && rows > 0 && C > 0, "colsum_bf16: bad args");
-  int rpb = (rows + 2047) / 2048;
+  int rpb = (rows + 1023) / 1024;      // <= 1024 workgroups: every one ends in C atomics on the same C words
   if (rpb < 64) rpb = 64;
   SDM_LAUNCH(colsum_bf16_kernel, dim3(cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)s, x, (long long)ldx, (long long)rows,
                      C, rpb, out);

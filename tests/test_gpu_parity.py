@@ -1213,6 +1213,23 @@ def test_cooperative_groupnorm_backward_matches_the_three_kernel_path_and_autogr
         assert float(ops.GNWS.get(n * c * 8, dev).abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("rows,C,ld", [(16384, 128, 128), (4096, 256, 256), (1000, 24, 24), (777, 64, 96), (50, 1536, 1536),
+                                       (300, 40, 40), (65, 3, 3), (9, 2052, 2052), (33, 130, 132), (4, 1024, 1024)])
+def test_colsum_fp32(dev, rows, C, ld):
+    """Column sums of fp32 rows (bias gradient of the transposed convs, train_diffusion.py:343-347 loss.backward()): the
+    16-byte-per-lane kernel on power-of-two and other channel counts, padded row pitches, more than 1024 channels and
+    C % 4 != 0 (element-wise form); overwrites or accumulates as asked."""
+    from sdm_hip import ops
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, ld, generator=g).to(dev)[:, :C]
+    ref = x.double().sum(0)
+    for accumulate in (True, False):
+        out = torch.full((C,), 0.5, device=dev)
+        ops.colsum(x, out, accumulate=accumulate)
+        want = (ref + (0.5 if accumulate else 0.0)).float()
+        assert torch.allclose(out, want, rtol=1e-5, atol=2e-5 * max(1.0, rows ** 0.5)), (accumulate, float((out - want).abs().max()))
+
+
 def test_launch_plan_replays_the_sampling_step(dev, O):
     """sdm_plan_begin / _end / _run: the captured DDPM / DDIM step replayed from the C-side launch plan gives the samples of
     graph replay and of eager launching (same Philox key), a plan holds exactly the library launches of one step, and a
