@@ -1608,6 +1608,183 @@ static int launch_wgrad(const WgradLaunch& L, int ntm, hipStream_t st) {
   return SDM_OK;
 }
 
+// --------------------------------------------------------------------------------------------
+// Weight gradient of the two EDGE convolutions (in_layer.0: Cin <= 4 -> C, out_layers.1: C -> Cout <= 4; U_Net.py:55-60,121-128;
+// autograd of their nn.Conv2d weights, train_diffusion.py:358).  One operand has <= 4 channels: on the 64x64 matrix-core tile the
+// contraction is 95 % padding and split 40 ways over the pixels (53 + 56 us of the 7.3 ms headline step at 2 TFLOP/s).  Here:
+//   dw[tap][..] += alpha * sum_q WIDE[q][c] * THIN[q + s * d_tap][t]          (s = +1: the activations are thin; -1: the gradient)
+// a workgroup takes R image rows of the wide operand (lane = wide channel, the spare lanes of a row walk further pixels), keeps
+// the thin operand's R + 2 rows in LDS as one 16-byte quad per pixel (rows are stored padded to 4 channels), holds the 9 x 3
+// partial sums of its channel in registers, and ends in one fp32 atomic per (tap, channel pair) and workgroup.
+// --------------------------------------------------------------------------------------------
+struct ThinWgradLaunch {
+  const float* wide;
+  const float* thin;
+  long long ld_wide;
+  float* dw;
+  long long w_tap_stride, stride_c, stride_t;
+  float* dbias_wide;   // += column sums of the wide operand (the gradient rows of the stem conv), or NULL
+  float* dbias_thin;   // += column sums of the thin operand (the gradient rows of the head conv), or NULL
+  int Cw, TH, images, H, W, R, sgn, lw;     // lw: log2(W) or -1
+  float alpha;
+  int tapw[9];                              // weight slice of tap t = (dy + 1) * 3 + (dx + 1)
+};
+
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(const ThinWgradLaunch L) {
+  extern __shared__ __align__(16) float thin_smem[];
+  f32x4* patch = (f32x4*)thin_smem;                        // [(R + 2) rows][W + 2] quads, zero outside the image
+  __shared__ float red[256][29];
+  const int tid = threadIdx.x, W = L.W, H = L.H, R = L.R, PW = W + 2;
+  const long long r0 = (long long)blockIdx.x * R;          // first image row (n * H + y) of this workgroup; R divides H
+  const int y0 = (int)(r0 % H);
+  for (int i = tid; i < (R + 2) * PW; i += 256) {
+    const int pr = i / PW, px = i - pr * PW;
+    const int y = y0 - 1 + pr, x = px - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = *(const f32x4*)(L.thin + ((r0 - 1 + pr) * W + x) * 4);
+    patch[i] = v;
+  }
+  __syncthreads();
+  int cw = 1;
+  while (cw < L.Cw) cw <<= 1;                              // lanes per pixel (Cw rounded up to a power of two <= 256)
+  const int c = tid % cw, pl = tid / cw, NPL = 256 / cw;
+  float acc[9][3];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t][0] = acc[t][1] = acc[t][2] = 0.f;
+  float bsum = 0.f;
+  const int npix = R * W, sgn = L.sgn;
+  if (c < L.Cw) {
+    const float* wp = L.wide + r0 * W * L.ld_wide + c;
+    for (int i0 = pl; i0 < npix; i0 += 8 * NPL) {          // eight pixels per trip: their loads overlap
+      float wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j * NPL;
+        wv[j] = i < npix ? wp[(long long)i * L.ld_wide] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j * NPL;                        // (a pixel beyond the range carries wv = 0 and reads inside the patch)
+        const int ii = i < npix ? i : 0;
+        const int yy = L.lw >= 0 ? ii >> L.lw : ii / W, x = ii - yy * W;
+        const f32x4* pc = patch + (yy + 1) * PW + x + 1;
+        bsum += wv[j];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {                      // taps in kernel order: (dy, dx) = (t / 3 - 1, t % 3 - 1)
+          const f32x4 th = pc[sgn * ((t / 3 - 1) * PW + (t % 3 - 1))];
+          acc[t][0] = fmaf(wv[j], th[0], acc[t][0]);
+          acc[t][1] = fmaf(wv[j], th[1], acc[t][1]);
+          acc[t][2] = fmaf(wv[j], th[2], acc[t][2]);
+        }
+      }
+    }
+  }
+  // pixel lanes of one channel meet in LDS; then one atomic per (tap, thin channel) and wide channel
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    red[tid][3 * t] = acc[t][0];
+    red[tid][3 * t + 1] = acc[t][1];
+    red[tid][3 * t + 2] = acc[t][2];
+  }
+  red[tid][27] = bsum;
+  __syncthreads();
+  {   // outputs in MEMORY order (lanes on consecutive words of a tap's slice: the atomics of a wave share cache lines)
+    const int per_tap = L.Cw * L.TH;
+    for (int e = tid; e < 9 * per_tap; e += 256) {
+      const int t = e / per_tap, rem = e - t * per_tap;
+      int cc, th;
+      if (L.stride_t == 1) { cc = rem / L.TH; th = rem - cc * L.TH; }     // dw[tap][wide][thin]
+      else { th = rem / L.Cw; cc = rem - th * L.Cw; }                     // dw[tap][thin][wide]
+      float v = 0.f;
+      for (int q = 0; q < NPL; ++q) v += red[q * cw + cc][3 * t + th];
+      atomicAdd(&L.dw[(long long)L.tapw[t] * L.w_tap_stride + cc * L.stride_c + th * L.stride_t], L.alpha * v);
+    }
+    if (L.dbias_wide)
+      for (int cc = tid; cc < L.Cw; cc += 256) {
+        float v = 0.f;
+        for (int q = 0; q < NPL; ++q) v += red[q * cw + cc][27];
+        atomicAdd(&L.dbias_wide[cc], v);
+      }
+  }
+  if (L.dbias_thin) {                                      // column sums of the thin operand over this workgroup's own pixels
+    f32x4 part = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < npix; i += 256) {
+      const int yy = L.lw >= 0 ? i >> L.lw : i / W, x = i - yy * W;
+      part += patch[(yy + 1) * PW + x + 1];
+    }
+    __shared__ float bred[4][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float v = wave_sum(part[k]);
+      if ((tid & 63) == 0) bred[tid >> 6][k] = v;
+    }
+    __syncthreads();
+    // ONE atomic per workgroup and channel: every workgroup of the launch adds to the same <= 3 words, and same-address atomics
+    // serialise (four per workgroup made the 128 -> 3 gradient of the headline step 33 us slower)
+    if (tid < L.TH) atomicAdd(&L.dbias_thin[tid], (bred[0][tid] + bred[1][tid]) + (bred[2][tid] + bred[3][tid]));
+  }
+}
+
+static int wgrad_thin_launch(const ThinWgradLaunch& L, const sdm_wgrad_desc* d, size_t lds, hipStream_t st) {
+  sdm_prof_pre(st);
+  SDM_LAUNCH(wgrad_thin_kernel, dim3((unsigned)((long)d->images * d->Hk / L.R)), dim3(256), lds, st, L);
+  sdm_prof_post(st, 4, 2.0 * d->M * d->N * (double)d->images * d->Hk * d->Wk * 9);
+  SDM_CHECK_LAUNCH("wgrad_thin");
+  return SDM_OK;
+}
+
+// the edge-conv form of a weight gradient: 3x3 taps on one pixel grid, one operand of <= 3 channels stored as 4-float rows
+static bool wgrad_thin_try(const sdm_wgrad_desc* d, hipStream_t st, int* rc) {
+  static const char* sw = getenv("SDM_WGRAD_THIN");        // "0": the matrix-core path for every shape (A/B)
+  if (sw && sw[0] == '0') return false;
+  if (d->batch != 1 || d->ntaps != 9 || d->g_stride != 1 || d->x_stride != 1 || d->accumulate == 0) return false;
+  if (d->x.p1 != nullptr || d->x.scale != nullptr) return false;
+  if (d->g.H != d->Hk || d->g.W != d->Wk || d->x.H != d->Hk || d->x.W != d->Wk) return false;
+  const bool thin_x = d->N <= 3 && d->M > 4 && d->M <= 256, thin_g = d->M <= 3 && d->N > 4 && d->N <= 256;
+  if (!thin_x && !thin_g) return false;
+  for (int t = 0; t < 9; ++t)      // taps in kernel order (the table conv_wgrad hands in for a 3x3 stride-1 conv)
+    if (d->g_dy[t] != 0 || d->g_dx[t] != 0 || d->x_dy[t] != t / 3 - 1 || d->x_dx[t] != t % 3 - 1) return false;
+  const sdm_rows& thin = thin_x ? d->x : d->g;
+  const sdm_rows& wide = thin_x ? d->g : d->x;
+  if (thin.ld0 != 4 || !aligned16(thin.p0)) return false;
+  ThinWgradLaunch L;
+  L.wide = wide.p0;
+  L.thin = thin.p0;
+  L.ld_wide = wide.ld0;
+  L.dw = d->dw;
+  L.w_tap_stride = d->w_tap_stride;
+  L.stride_c = thin_x ? d->ldw : 1;                        // dw[tap][i = gradient channel][j = activation channel]
+  L.stride_t = thin_x ? 1 : d->ldw;
+  L.dbias_wide = thin_x ? d->dbias : nullptr;
+  L.dbias_thin = thin_x ? nullptr : d->dbias;
+  L.Cw = thin_x ? d->M : d->N;
+  L.TH = thin_x ? d->N : d->M;
+  L.images = d->images;
+  L.H = d->Hk;
+  L.W = d->Wk;
+  L.sgn = thin_x ? 1 : -1;   // sum_p G[p] X[p + d]: thin X sits at +d of the wide pixel; thin G at -d of the wide (X) pixel
+  L.alpha = d->alpha;
+  for (int t = 0; t < 9; ++t) L.tapw[t] = d->tap_w[t];
+  L.lw = -1;
+  for (int b = 0; b < 30; ++b)
+    if ((1 << b) == d->Wk) L.lw = b;
+  // R image rows per workgroup: a divisor of H, >= 512 workgroups where the map allows, LDS patch <= 48 KB
+  static const char* mw_s = getenv("SDM_WGRAD_THIN_MINWG");      // tuning: fewest workgroups a larger R may leave
+  const long minwg = mw_s ? atol(mw_s) : 512;
+  int R = 1;
+  for (int r = 2; r <= d->Hk; ++r) {
+    if (d->Hk % r) continue;
+    if ((long)d->images * d->Hk / r < minwg || (size_t)(r + 2) * (d->Wk + 2) * 16 > 32 * 1024) break;
+    R = r;
+  }
+  if ((size_t)(R + 2) * (d->Wk + 2) * 16 > 32 * 1024) return false;
+  L.R = R;
+  const size_t lds = (size_t)(R + 2) * (d->Wk + 2) * 16;
+  sdm_prof_shape(d->M, d->N, (long)d->images * d->Hk * d->Wk, 9, 1, 4.0 * ((double)d->images * d->Hk * d->Wk * (L.Cw + 4) + 9.0 * d->M * d->N));
+  *rc = wgrad_thin_launch(L, d, lds, st);
+  return true;
+}
+
 extern "C" int sdm_wgrad(const sdm_wgrad_desc* d, sdm_stream_t stream) {
   SDM_CHECK_ARG(d != nullptr, "wgrad: null desc");
   SDM_CHECK_ARG(d->M > 0 && d->N > 0 && d->images > 0 && d->Hk > 0 && d->Wk > 0, "wgrad: bad dims");
@@ -1623,6 +1800,10 @@ extern "C" int sdm_wgrad(const sdm_wgrad_desc* d, sdm_stream_t stream) {
                                           d->x.aff_nstride % 4 == 0),
                 "wgrad: affine-on-load needs N %% 4 == 0 and aligned tables");
   hipStream_t st = (hipStream_t)stream;
+  {
+    int rc_thin = SDM_OK;
+    if (wgrad_thin_try(d, st, &rc_thin)) return rc_thin;
+  }
   WgradLaunch L;
   L.d = *d;
   const long P = (long)d->images * d->Hk * d->Wk;

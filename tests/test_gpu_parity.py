@@ -1213,6 +1213,34 @@ def test_cooperative_groupnorm_backward_matches_the_three_kernel_path_and_autogr
         assert float(ops.GNWS.get(n * c * 8, dev).abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("n,h,w,C,thin", [(4, 64, 64, 128, 3), (2, 16, 16, 64, 3), (3, 8, 8, 40, 1), (2, 32, 32, 256, 2),
+                                          (1, 128, 128, 128, 3), (2, 6, 10, 128, 3)])
+def test_edge_conv_weight_gradient_thin_kernel(dev, n, h, w, C, thin):
+    """Weight (+ bias) gradient of the two edge convs -- in_layer.0 (thin input -> C) and out_layers.1 (C -> thin output),
+    U_Net.py:55-60,121-128 -- through sdm_wgrad's thin-operand kernel (one operand of <= 3 channels stored as 4-float rows)
+    against torch autograd of the same Conv2d(k3, p1) on the same tensors; alpha / accumulate semantics as every other
+    weight gradient (added into the buffer)."""
+    from sdm_hip import lib, ops
+    g = torch.Generator().manual_seed(n * h + C + thin)
+    for cin, cout in ((thin, C), (C, thin)):
+        x = torch.randn(n, cin, h, w, generator=g).to(dev).requires_grad_(False)
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).to(dev).requires_grad_(True)
+        b = torch.zeros(cout, device=dev, requires_grad=True)
+        up = torch.randn(n, cout, h, w, generator=g).to(dev)
+        torch.nn.functional.conv2d(x, wt, b, padding=1).backward(up)
+        want_w = wt.grad.permute(2, 3, 0, 1).reshape(9, cout, cin)
+        rows = lambda t, pad: torch.nn.functional.pad(t.permute(0, 2, 3, 1).reshape(n * h * w, -1), (0, pad)).contiguous()
+        xr = rows(x, (4 - cin) if cin == thin else 0)
+        gr = rows(up, (4 - cout) if cout == thin else 0)
+        dw = torch.full((9, cout, cin), 0.25, device=dev)
+        db = torch.full((cout,), 0.5, device=dev)
+        l0 = lib.launch_count()
+        ops.conv_wgrad(gr[:, :cout], (h, w), ops.Act(xr[:, :cin], n, h, w), "c3s1", dw, accumulate=1, dbias=db)
+        assert lib.launch_count() - l0 == 1, (cin, cout, lib.launch_count() - l0)          # the thin kernel, no split / memset
+        assert rel(dw - 0.25, want_w) < 2e-5, (cin, cout, rel(dw - 0.25, want_w))
+        assert rel(db - 0.5, b.grad) < 2e-5, (cin, cout, rel(db - 0.5, b.grad))
+
+
 @pytest.mark.parametrize("rows,C,ld", [(16384, 128, 128), (4096, 256, 256), (1000, 24, 24), (777, 64, 96), (50, 1536, 1536),
                                        (300, 40, 40), (65, 3, 3), (9, 2052, 2052), (33, 130, 132), (4, 1024, 1024)])
 def test_colsum_fp32(dev, rows, C, ld):
